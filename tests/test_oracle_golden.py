@@ -1,0 +1,149 @@
+"""Pins the CPU oracle against every known answer the reference itself holds.
+CPU-only; the oracle is test infrastructure, never the product path."""
+import csv
+import json
+import os
+
+import numpy as np
+
+from oracle import np_oracle
+
+
+def _known(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "known_answers.json")))
+
+
+def test_returns_trajectory_csv(orc, golden_dir):
+    # reference/output/trajectory.csv:1-7 : six steps of reward 1, gamma=1 -> 6,5,4,3,2,1
+    rows = list(csv.DictReader(open(os.path.join(golden_dir, "trajectory.csv"))))
+    assert [r["sample_names"] for r in rows] == ["sample_%d.bson" % i for i in range(1, 7)]
+    expect = np.array([float(r["returns"]) for r in rows], np.float32)
+    assert all(int(r["selected_actions"]) == 4 for r in rows)
+    assert all(float(r["selected_action_probabilities"]) == 0.5 for r in rows)
+    rewards = np.ones(6, np.float32)
+    for last_terminal in (0, 1):      # the CSV does not record the flag of the final row
+        term = np.array([0, 0, 0, 0, 0, last_terminal], np.uint8)
+        for f32 in (False, True):
+            got = orc.compute_returns(rewards, term, 1.0, f32)
+            assert np.array_equal(got, expect)
+        assert np.array_equal(np_oracle.compute_returns(rewards, term, 1.0), expect)
+
+
+def test_returns_test_env(orc, golden_dir):
+    # reference/test/test_rollout_buffer.jl:4-50: 10 episodes x horizon 10, reward 1.0, gamma 1.0
+    k = _known(golden_dir)["returns_test_env"]
+    n = k["episodes"] * k["horizon"]
+    rewards = np.full(n, k["reward"], np.float32)
+    term = np.zeros(n, np.uint8)
+    term[k["horizon"] - 1::k["horizon"]] = 1
+    expect = np.tile(np.array(k["returns_per_episode"], np.float32), k["episodes"])
+    assert np.array_equal(orc.compute_returns(rewards, term, k["discount"]), expect)
+    assert np.array_equal(np_oracle.compute_returns(rewards, term, k["discount"]), expect)
+    # time-major layout: 10 envs in parallel, one episode each
+    got = orc.compute_returns_tn(rewards.reshape(10, 10).T.copy(), term.reshape(10, 10).T.copy(), 1.0)
+    assert np.array_equal(got, expect.reshape(10, 10).T)
+
+
+def test_index_to_action(orc, golden_dir):
+    k = _known(golden_dir)["index_to_action_triangle"]
+    for idx, exp in k["cases"]:      # notebook known answers (3 edges x 2 types)
+        quad, edge, typ = np_oracle.index_to_action(idx, k["actions_per_edge"])
+        # triangle variant has 3 edges: same formula with actions_per_quad = 3*2
+        apq = k["edges"] * k["actions_per_edge"]
+        q = (idx - 1) // apq + 1
+        qa = (idx - 1) % apq
+        assert [q, qa // k["actions_per_edge"] + 1, qa % k["actions_per_edge"] + 1] == exp
+    # quad variant (test/quad_game_utilities.jl:95-105): exhaustive agreement C vs numpy
+    for idx in range(1, 16 * 8 + 1):
+        assert orc.index_to_action(idx) == np_oracle.index_to_action(idx)
+    assert orc.index_to_action(1) == (1, 1, 1)
+    assert orc.index_to_action(16) == (1, 4, 4)
+    assert orc.index_to_action(17) == (2, 1, 1)
+    assert orc.index_to_action(22) == (2, 2, 2)
+
+
+def test_mask_pattern(orc, golden_dir):
+    k = _known(golden_dir)["mask_pattern"]
+    # notebook: 2 of 4 triangles active, 6 actions each -> 12 zeros then 12 -Inf
+    m = np_oracle.action_mask(np.array(k["active"], bool), actions_per_edge=k["per_quad"] // 4 if False else 4)
+    m4 = orc.action_mask(np.array(k["active"], np.uint8))
+    assert np.array_equal(m, m4)
+    assert np.all(m4[:32] == 0.0) and np.all(np.isneginf(m4[32:]))
+    # the notebook's own pattern (6 actions per element)
+    req = np.repeat(~np.array(k["active"], bool), k["per_quad"])
+    pat = np.where(req, -np.inf, 0.0)
+    assert (pat[:k["expect_zero"]] == 0).all() and np.isneginf(pat[k["expect_zero"]:]).all()
+    assert len(pat) == k["expect_zero"] + k["expect_neginf"]
+
+
+def test_philox_kat(orc, golden_dir):
+    for c in _known(golden_dir)["philox4x32_10_kat"]["cases"]:
+        exp = np.array([int(x, 16) for x in c["out"]], np.uint32)
+        assert np.array_equal(orc.philox(c["ctr"], c["key"]), exp)
+        assert np.array_equal(np_oracle.philox4x32_10(c["ctr"], c["key"]), exp)
+
+
+def test_masked_softmax_property(orc, golden_dir):
+    # notebook :742-767: masked entries exactly 0.0, the rest sums to 1
+    z = np.load(os.path.join(golden_dir, "poly-30-policy.npz"))
+    params = z["params"]
+    rng = np.random.default_rng(0)
+    x = rng.integers(-2, 5, size=(32, 72)).astype(np.int8)
+    active = 0b00111111
+    for mode in ("ref", "dev"):
+        p = orc.action_probabilities(params, 72, 128, x, active, mode)
+        assert np.all(p[96:] == 0.0)
+        assert abs(float(p.sum()) - 1.0) < 1e-6
+        assert np.all(p[:96] >= 0) and p[:96].max() > 0   # trained weights on random inputs: may underflow
+
+
+def test_sampler_invariant(orc):
+    # src/collect_rollouts.jl:7  @assert ap[a] > 0.0
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        p = rng.random(128).astype(np.float32)
+        p[rng.random(128) < 0.3] = 0
+        p[5] = 0.25
+        p = (p / p.sum(dtype=np.float32)).astype(np.float32)
+        u = np.float32(rng.random())
+        a, err = orc.categorical_sample(p, u)
+        assert a == np_oracle.categorical_sample(p, u)
+        # the sequential walk can only stop on a zero-prob entry by clamping at the end
+        if err:
+            assert a == 127
+        else:
+            assert p[a] > 0
+    # clamp case: trailing zeros and u above the total mass
+    p = np.zeros(8, np.float32)
+    p[0] = 0.5
+    a, err = orc.categorical_sample(p, 0.75)
+    assert (a, err) == (7, 1)
+
+
+def test_clip_identity(orc):
+    # min(rho*A, simplified_clip(A,eps)) == min(rho*A, clamp(rho,1-eps,1+eps)*A)
+    rng = np.random.default_rng(2)
+    for _ in range(1000):
+        rho, adv, eps = float(rng.random() * 3 + 1e-3), float(rng.normal()), 0.05
+        lhs = min(rho * adv, orc.simplified_ppo_clip(adv, eps))
+        rhs = min(rho * adv, min(max(rho, 1 - eps), 1 + eps) * adv)
+        assert abs(lhs - rhs) < 1e-12
+
+
+def test_disk_fixture_bytes(golden_dir):
+    # output/states/sample_1.bson: {state: Int64[1,2,3,4,5]} (183 B) -- wire format fixture
+    import bson
+    raw = open(os.path.join(golden_dir, "sample_1.bson"), "rb").read()
+    assert len(raw) == 183
+    d = bson.decode(raw)
+    st = d["state"]
+    assert st["tag"] == "array" and st["size"] == [5]
+    assert np.array_equal(np.frombuffer(st["data"], "<i8"), [1, 2, 3, 4, 5])
+
+
+def test_weight_fixture_shapes(golden_dir, orc):
+    for name, F in (("catmull-clark-policy-l4", 216), ("poly-30-policy", 72), ("catmull-clark-policy", 72)):
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        assert z["params"].size == orc.mlp_num_params(F, 128, 2)
+        assert z["shapes"].tolist() == [[128, F], [128, 0], [128, 128], [128, 0], [4, 128], [4, 0]]
+        assert np.isfinite(z["params"]).all()
