@@ -161,7 +161,7 @@ def test_env_invariants(orc):
             a = 16 * q + int(rng.integers(0, 16))
             env.step_one(n, a)
             assert env.err[n] == 0
-            assert -4.0 <= float(env.reward[n]) <= 4.0
+            assert -8.0 <= float(env.reward[n]) <= 16.0   # collapse removes a whole quad from the total
             # desired degree = score + degree is conserved: 3 or 4 on active quads, 0 elsewhere
             des = env.score[n].astype(int) + env.degree[n].astype(int)
             actq = np.repeat([(int(env.active[n]) >> q) & 1 for q in range(8)], 4).astype(bool)
