@@ -1,0 +1,199 @@
+/*
+ * ppo_hip.h -- C ABI of libppo_hip.so, the MI355X (gfx950) engine behind the
+ * ProximalPolicyOptimization.jl rollout-and-update path.
+ *
+ * The reference has NO FFI: its boundary is Julia multiple dispatch on the generic functions of
+ * module ProximalPolicyOptimization (src/ProximalPolicyOptimization.jl:16-30).  Each entry point
+ * below names the reference function it stands in for; the Julia-side binding (ccall methods for
+ * HipVecEnv / HipPolicy / HipRollouts) is in julia/ProximalPolicyOptimizationHIP.jl and
+ * INTEGRATION.md.  The Python mirror used by the tests is proximalpolicyoptimization.jl_amd/.
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 = ok, <0 = error; ppo_last_error() gives the text.
+ *    (reference: ErrorException / AssertionError, SURVEY.md 8(b) "Errors")
+ *  - every pointer is a HOST pointer owned by the caller unless the name ends in _dev;
+ *    getters copy into caller buffers; handles own all device memory.
+ *  - action indices crossing this ABI are 0-based int32 (Julia shim adds/subtracts 1).
+ *  - layouts: rollout columns are time-major [T,N]; states are int8 [.,H,F] (row = half-edge,
+ *    F = 72 features: 36 template scores then 36 template degrees); the action mask travels as
+ *    the active-quad bit mask (bit q set = quad q active; entries a with quad a/16 inactive are
+ *    -Inf in the reference, test/quad_game_utilities.jl:39-44).
+ *  - policy parameters are one flat float32 vector in Flux order (W1,b1,W2,b2,W3,b3), W stored
+ *    [out,in] column-major, so Flux.params(policy) round-trips (test/policy.jl:9-19).
+ *  - not re-entrant per handle; one host thread and one HIP stream per process (ppo_set_stream).
+ */
+#ifndef PPO_HIP_H
+#define PPO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ppo_env_s* ppo_env_t;
+typedef struct ppo_policy_s* ppo_policy_t;
+typedef struct ppo_adam_s* ppo_adam_t;
+typedef struct ppo_rollouts_s* ppo_rollouts_t;
+
+#define PPO_OK 0
+#define PPO_ERR_ARG (-1)        /* bad argument / failed @assert-equivalent            */
+#define PPO_ERR_HIP (-2)        /* HIP runtime error                                   */
+#define PPO_ERR_DEVICE_FLAG (-3)/* device-side error flag (zero-prob action sampled,   */
+                                /* invalid action index, stepping a terminated env)    */
+#define PPO_ERR_UNSUPPORTED (-4)
+
+/* advantage plugin modes (batch_advantage, src/ProximalPolicyOptimization.jl:29; no
+ * implementation exists in the reference, old scripts use raw returns) */
+#define PPO_ADV_RETURNS 0
+#define PPO_ADV_RETURNS_NORMALISED 1
+
+/* ---------------------------------------------------------------- library / device */
+int32_t ppo_version(void);
+int32_t ppo_last_error(char* buf, int64_t cap);
+int32_t ppo_device_init(int32_t device_ordinal);          /* hipSetDevice + private stream     */
+int32_t ppo_set_stream(void* hip_stream);                 /* run on an external hipStream_t     */
+int32_t ppo_device_synchronize(void);
+int32_t ppo_device_count(int32_t* out);
+
+/* ---------------------------------------------------------------- standalone ops (parity entry points) */
+/* compute_returns(rewards, terminal, discount)            src/collect_rollouts.jl:26-42
+ * flat concatenated-episodes semantics; discount_is_f32=0 reproduces the Float64 running value */
+int32_t ppo_compute_returns(const float* rewards, const uint8_t* terminal, int64_t n,
+                            double discount, int32_t discount_is_f32, float* out);
+/* same scan on time-major [T,N] columns (v=0 at each column tail) -- the engine's hot layout */
+int32_t ppo_compute_returns_tn(const float* rewards, const uint8_t* done, int64_t T, int64_t N,
+                               double discount, int32_t discount_is_f32, float* out);
+/* GAE(gamma,lambda) extension (values [T+1,N]); lambda=1, V=0 == ppo_compute_returns_tn */
+int32_t ppo_gae_tn(const float* rewards, const uint8_t* done, const float* values, int64_t T,
+                   int64_t N, double gamma, double lambda, float* adv_out, float* ret_out);
+/* rand(Categorical(p)) for B rows of A probabilities given B uniforms   src/collect_rollouts.jl:6-7
+ * actions 0-based; err[b]=1 when the sampled entry has p==0 (the reference's @assert) */
+int32_t ppo_categorical_sample(const float* probs, const float* u, int64_t B, int64_t A,
+                               int32_t* actions, float* p_sel, int32_t* err);
+/* get_linear_action_index (1-based in, 1-based out)        src/train.jl:48-52 */
+int32_t ppo_linear_action_index(const int64_t* actions1, int64_t B, int64_t A, int64_t* out);
+/* ppo_loss_with_entropy on given probs [A,B] (column-major), 1-based linear indices
+ *                                                          src/train.jl:21-26,35-46 */
+int32_t ppo_loss_with_entropy(const float* probs, const int64_t* lin_idx1, const float* p_old,
+                              const float* adv, int64_t B, int64_t A, double epsilon,
+                              double* ppoloss, double* entropyloss);
+/* counter RNG exposed for tests: Philox4x32-10 */
+int32_t ppo_philox4x32_10(const uint32_t* ctr4, const uint32_t* key2, int64_t n, uint32_t* out4);
+
+/* ---------------------------------------------------------------- env plugin (batched) */
+/* PPO.state / reward / is_terminal / reset! / step!        src/ProximalPolicyOptimization.jl:16-20
+ * kind 0 = synthetic rand-poly-shaped env (Q quad slots, H=4Q half-edges, A=16Q actions) */
+int32_t ppo_env_create(int32_t kind, int64_t num_envs, int64_t global_env_offset, int32_t Q,
+                       int32_t max_actions, float no_action_reward, uint64_t seed, ppo_env_t* out);
+int32_t ppo_env_destroy(ppo_env_t env);
+int32_t ppo_env_dims(ppo_env_t env, int64_t* N, int32_t* H, int32_t* F, int32_t* A);
+int32_t ppo_env_reset(ppo_env_t env);                                   /* reset!      :19 */
+int32_t ppo_env_step(ppo_env_t env, const int32_t* actions0);           /* step!       :20 */
+int32_t ppo_env_get_state(ppo_env_t env, int8_t* obs, uint32_t* active);/* state       :16 */
+int32_t ppo_env_get_reward(ppo_env_t env, float* out);                  /* reward      :17 */
+int32_t ppo_env_get_terminal(ppo_env_t env, uint8_t* out);              /* is_terminal :18 */
+int32_t ppo_env_get_internal(ppo_env_t env, int8_t* score, int8_t* degree, int32_t* steps,
+                             uint32_t* episode, uint32_t* tick);
+int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null);
+
+/* ---------------------------------------------------------------- policy plugin */
+/* SimplePolicy.Policy(in, hidden, num_hidden_layers, out)  test/policy.jl:9-19 */
+int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers,
+                          int32_t out_per_edge, ppo_policy_t* out);
+int32_t ppo_policy_destroy(ppo_policy_t pol);
+int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n);
+int32_t ppo_policy_set_params(ppo_policy_t pol, const float* flat);     /* Flux.params order */
+int32_t ppo_policy_get_params(ppo_policy_t pol, float* flat);
+/* batch_action_probabilities(policy, state) -> probs [A,B] column-major (B=1: action_probabilities)
+ *                                                          test/quad_game_utilities.jl:65-79 */
+int32_t ppo_policy_forward(ppo_policy_t pol, const int8_t* states, const uint32_t* active,
+                           int64_t B, int32_t H, float* probs);
+/* flat gradient of the last ppo_forward_backward (Flux order) */
+int32_t ppo_policy_get_grad(ppo_policy_t pol, float* flat);
+/* device pointer to the flat gradient buffer [num_params + 2] (grad, ppo-sum, entropy-sum):
+ * the hand-off point for the data-parallel all-reduce (RCCL through torch.distributed) */
+int32_t ppo_policy_grad_buffer_dev(ppo_policy_t pol, void** dev_ptr, int64_t* n_floats);
+
+/* ---------------------------------------------------------------- optimiser */
+/* Flux.Optimiser(Adam(eta,(beta1,beta2),eps)) + Flux.update!            src/train.jl:81,155-158 */
+int32_t ppo_adam_create(ppo_policy_t pol, double eta, double beta1, double beta2, double eps,
+                        ppo_adam_t* out);
+int32_t ppo_adam_destroy(ppo_adam_t opt);
+int32_t ppo_adam_get_lr(ppo_adam_t opt, double* eta);                    /* get_optimizer_learning_rate */
+int32_t ppo_adam_set_lr(ppo_adam_t opt, double eta);
+int32_t ppo_adam_get_state(ppo_adam_t opt, float* m, float* v, double* beta_pow2);
+int32_t ppo_adam_set_state(ppo_adam_t opt, const float* m, const float* v, const double* beta_pow2);
+
+/* ---------------------------------------------------------------- rollout buffer */
+/* BufferRollouts()                                          src/rollout_buffer.jl:1-22 */
+int32_t ppo_rollouts_create(ppo_env_t env, int64_t capacity_T, ppo_rollouts_t* out);
+int32_t ppo_rollouts_destroy(ppo_rollouts_t ro);
+int32_t ppo_rollouts_len(ppo_rollouts_t ro, int64_t* n);                 /* Base.length :40-48 */
+int32_t ppo_rollouts_dims(ppo_rollouts_t ro, int64_t* T, int64_t* N);
+/* collect_rollouts!(rollouts, env, policy, ., discount)     src/rollout_buffer.jl:66-79
+ * fixed-T vectorised form: T steps of all N envs with auto-reset, then compute_state_value!
+ * (returns overwrite rewards, :55-64).  record_probs!=0 additionally keeps the full [T,N,A]
+ * probabilities (tests only). */
+int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t T,
+                             double discount, int32_t discount_is_f32, int32_t record_probs);
+/* num_episodes form: every env plays `episodes_per_env` complete episodes (reference semantics:
+ * only whole episodes enter the buffer); dataset length = number of valid transitions */
+int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
+                                      int64_t episodes_per_env, double discount,
+                                      int32_t discount_is_f32);
+/* column getters, time-major [T,N] (dataset getindex, src/rollout_buffer.jl:103-133) */
+int32_t ppo_rollouts_get_states(ppo_rollouts_t ro, int8_t* states, uint32_t* active);
+int32_t ppo_rollouts_get_actions(ppo_rollouts_t ro, int32_t* actions0);
+int32_t ppo_rollouts_get_probs(ppo_rollouts_t ro, float* p_sel);
+int32_t ppo_rollouts_get_returns(ppo_rollouts_t ro, float* returns);     /* "rewards" after :55-64 */
+int32_t ppo_rollouts_get_raw_rewards(ppo_rollouts_t ro, float* rewards);
+int32_t ppo_rollouts_get_terminal(ppo_rollouts_t ro, uint8_t* terminal);
+int32_t ppo_rollouts_get_valid(ppo_rollouts_t ro, uint8_t* valid);
+int32_t ppo_rollouts_get_full_probs(ppo_rollouts_t ro, float* probs);   /* [T,N,A], record_probs only */
+/* dataset order: flat index list of the valid transitions (t*N+n), length = ppo_rollouts_len */
+int32_t ppo_rollouts_get_index(ppo_rollouts_t ro, int64_t* idx);
+/* load columns from host (tests / generic host-side envs) */
+int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, const uint32_t* active,
+                         const int32_t* actions0, const float* p_sel, const float* returns,
+                         const uint8_t* terminal);
+
+/* ---------------------------------------------------------------- training */
+/* forward + loss + backward of one minibatch given dataset positions `sample_idx` (0-based
+ * positions into the dataset order).  Leaves the flat gradient (mean over B_global) in the
+ * policy's gradient buffer.  B_global = minibatch size across all data-parallel ranks.
+ *                                                          src/train.jl:35-46,65-79 */
+int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t* sample_idx,
+                             int64_t B, int64_t B_global, double epsilon, double entropy_weight,
+                             int32_t adv_mode);
+/* Flux.update!(optimizer, weights, grad)                    src/train.jl:81 */
+int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol);
+/* losses of the last forward_backward (after any all-reduce): (ppoloss, entropy_weight*entropyloss)
+ *                                                          src/train.jl:83 */
+int32_t ppo_last_losses(ppo_policy_t pol, double* ppoloss, double* entropyloss);
+/* step_batch!                                               src/train.jl:54-84 */
+int32_t ppo_step_batch(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro,
+                       const int64_t* sample_idx, int64_t B, double epsilon, double entropy_weight,
+                       int32_t adv_mode, double* ppoloss, double* entropyloss);
+/* all-reduce hook: called once per optimiser step between backward and Adam with the device
+ * gradient buffer (sum over ranks expected on return, enqueued on / ordered with the stream) */
+typedef int32_t (*ppo_allreduce_fn)(void* ctx, void* grad_dev, int64_t n_floats);
+/* ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight)
+ *                                                          src/train.jl:86-153
+ * perm: NULL -> device Feistel permutation keyed by (seed, epoch counter), else num_epochs
+ * explicit 0-based permutations of length len (randperm, :93).  hist arrays have num_epochs
+ * entries: mean per-batch losses and the learning rate (:127,144-150).
+ * world = data-parallel ranks (minibatch per rank = batch_size, global = world*batch_size). */
+int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon,
+                  int64_t batch_size, int32_t num_epochs, double entropy_weight, int32_t adv_mode,
+                  const int64_t* perm, uint64_t seed, int32_t world, ppo_allreduce_fn allreduce,
+                  void* allreduce_ctx, double* ppo_hist, double* entropy_hist, double* lr_hist);
+
+/* timing of the dominant kernels of the last ppo_train / ppo_collect_rollouts call, measured with
+ * HIP events on the engine's stream (bench.py roofline leg) */
+int32_t ppo_profile_enable(int32_t on);
+int32_t ppo_profile_get(const char* kernel_name, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,728 @@
+"""Host-side mirror of module ProximalPolicyOptimization (reference: src/ProximalPolicyOptimization.jl)
+over the C ABI of libppo_hip.so (include/ppo_hip.h).
+
+Julia is not available in the build image, so the host language above the C ABI is Python; the
+Julia `ccall` shim a maintainer would use is julia/ProximalPolicyOptimizationHIP.jl.
+Names, argument order and error behaviour follow the reference:
+
+    Julia                                   here
+    ------------------------------------    -------------------------------------------
+    PPO.state / reward / is_terminal        state(env) / reward(env) / is_terminal(env)
+    PPO.reset!(env) / PPO.step!(env, a)     reset_(env) / step_(env, a)          (a is 1-based)
+    PPO.action_probabilities(policy, s)     action_probabilities(policy, s)
+    PPO.batch_action_probabilities          batch_action_probabilities(policy, s)
+    PPO.batch_state / number_of_actions_per_state / batch_advantage / save_loss   same names
+    PPO.BufferRollouts()                    BufferRollouts()
+    PPO.collect_rollouts!(r, env, p, n, g)  collect_rollouts_(r, env, p, n, g)
+    PPO.compute_returns(r, t, g)            compute_returns(r, t, g)
+    PPO.construct_dataset(r)                construct_dataset(r);  len(ds);  ds[i] / ds[[i,...]] (1-based)
+    PPO.ppo_train!(...)                     ppo_train_(...)
+    PPO.ppo_iterate!(...)                   ppo_iterate_(...)
+    Flux.Optimiser(Adam(1e-4))              Optimiser(Adam(1e-4))
+
+Plugin functions are generic: calling one on an object that does not overload it raises
+`PPOError("Function <name> needs to be overloaded")` like src/ProximalPolicyOptimization.jl:12-14.
+Indices that cross this API are 1-based like the reference; the C ABI below is 0-based.
+All compute runs in the HIP library; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import functools
+
+import numpy as np
+
+from . import _lib
+from ._lib import PPOError, call, lib
+
+__all__ = [
+    "PPOError", "HipVecEnv", "HipPolicy", "Adam", "Optimiser", "StateData", "BufferRollouts", "BufferDataset",
+    "state", "reward", "is_terminal", "reset_", "step_", "action_probabilities", "batch_action_probabilities",
+    "batch_state", "number_of_actions_per_state", "batch_advantage", "save_loss", "compute_returns",
+    "compute_returns_tn", "gae_tn", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
+    "simplified_ppo_clip", "get_linear_action_index", "ppo_loss_with_entropy", "categorical_sample", "step_batch_",
+    "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
+    "device_count", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
+]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _not_implemented(name):
+    raise PPOError(-1, "Function %s needs to be overloaded" % name)       # src/ProximalPolicyOptimization.jl:12-14
+
+
+def _generic(name):
+    @functools.singledispatch
+    def f(obj, *a, **k):
+        _not_implemented(name)
+    f.__name__ = name
+    return f
+
+
+# ---- plugin generic functions (src/ProximalPolicyOptimization.jl:16-30)
+state = _generic("state")
+reward = _generic("reward")
+is_terminal = _generic("is_terminal")
+reset_ = _generic("reset!")
+step_ = _generic("step!")
+action_probabilities = _generic("action_probabilities")
+batch_action_probabilities = _generic("batch_action_probabilities")
+batch_state = _generic("batch_state")
+number_of_actions_per_state = _generic("number_of_actions_per_state")
+batch_advantage = _generic("batch_advantage")
+save_loss = _generic("save_loss")
+
+
+def device_count():
+    return _lib.device_count()
+
+
+def synchronize():
+    call("ppo_device_synchronize")
+
+
+def profile_enable(on=True):
+    call("ppo_profile_enable", int(bool(on)))
+
+
+def profile_get(name):
+    ms, n = C.c_double(0), C.c_int64(0)
+    call("ppo_profile_get", name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value
+
+
+# ------------------------------------------------------------------ state container (test/quad_game_utilities.jl:17-20)
+class StateData:
+    """vertex_score: int8 [H,F] (single) or [B,H,F] (batched); action_mask: active-quad bit mask(s).
+
+    The reference stores the [F,H] Int matrix and a Float32 {0,-Inf} mask vector; here the same
+    information travels as the row-per-half-edge int8 matrix and the active-quad bits the mask is
+    built from (action_mask(), test/quad_game_utilities.jl:39-44)."""
+
+    def __init__(self, vertex_score, action_mask):
+        self.vertex_score = vertex_score
+        self.action_mask = action_mask
+
+    def mask_vector(self, actions_per_edge=4):
+        bits = np.atleast_1d(np.asarray(self.action_mask, np.uint32))
+        Hh = self.vertex_score.shape[-2]
+        q = np.arange(Hh * actions_per_edge) // (4 * actions_per_edge)
+        m = np.where((bits[:, None] >> q[None, :]) & 1, np.float32(0), np.float32(-np.inf))
+        return m[0] if np.ndim(self.action_mask) == 0 else m
+
+
+@batch_state.register(list)
+def _(states):
+    """PPO.batch_state (test/quad_game_utilities.jl:26-33): cat along the batch dimension."""
+    vs = np.stack([np.asarray(s.vertex_score, np.int8) for s in states])
+    am = np.array([np.uint32(s.action_mask) for s in states], np.uint32)
+    return StateData(vs, am)
+
+
+@number_of_actions_per_state.register(StateData)
+def _(s):
+    return int(s.vertex_score.shape[-2]) * 4          # default: size(mask, 1)  
+
+
+@batch_advantage.register(StateData)
+def _(s, returns):
+    return np.asarray(returns, np.float32)             # reference scripts use raw returns as advantage
+
+
+def index_to_action(index, actions_per_edge=4):
+    """test/quad_game_utilities.jl:95-105 (1-based)."""
+    apq = 4 * actions_per_edge
+    quad = (index - 1) // apq + 1
+    qa = (index - 1) % apq
+    return quad, qa // actions_per_edge + 1, qa % actions_per_edge + 1
+
+
+def action_mask(active_quad, actions_per_edge=4):
+    """test/quad_game_utilities.jl:39-44."""
+    req = np.repeat(~np.asarray(active_quad, bool), 4 * actions_per_edge)
+    return np.where(req, -np.inf, 0.0).astype(np.float32)
+
+
+# ------------------------------------------------------------------ env
+class HipVecEnv:
+    """N synthetic rand-poly-shaped envs resident on the GPU (ppo_env_*).  Not QuadMeshGame: the
+    mesh dynamics are not in the reference tree ('Synthetic env')."""
+
+    def __init__(self, num_envs=1, Q=8, max_actions=128, no_action_reward=-4.0, seed=1234, global_offset=0):
+        h = C.c_void_p()
+        call("ppo_env_create", 0, int(num_envs), int(global_offset), int(Q), int(max_actions), float(no_action_reward),
+             int(seed), C.byref(h))
+        self._h = h
+        self.N, self.Q, self.H, self.F, self.A = int(num_envs), Q, 4 * Q, 72, 16 * Q
+        self.max_actions = max_actions
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ppo_env_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def internal(self):
+        V = 4 * self.Q
+        sc = np.empty((self.N, V), np.int8)
+        dg = np.empty((self.N, V), np.int8)
+        st = np.empty(self.N, np.int32)
+        ep = np.empty(self.N, np.uint32)
+        tk = np.empty(self.N, np.uint32)
+        call("ppo_env_get_internal", self._h, _p(sc, _lib.c_i8p), _p(dg, _lib.c_i8p), _p(st, _lib.c_i32p),
+             _p(ep, _lib.c_u32p), _p(tk, _lib.c_u32p))
+        return dict(score=sc, degree=dg, steps=st, episode=ep, tick=tk)
+
+
+@state.register(HipVecEnv)
+def _(env):
+    obs = np.empty((env.N, env.H, env.F), np.int8)
+    act = np.empty(env.N, np.uint32)
+    call("ppo_env_get_state", env._h, _p(obs, _lib.c_i8p), _p(act, _lib.c_u32p))
+    return StateData(obs[0], act[0]) if env.N == 1 else StateData(obs, act)
+
+
+@reward.register(HipVecEnv)
+def _(env):
+    r = np.empty(env.N, np.float32)
+    call("ppo_env_get_reward", env._h, _p(r, _lib.c_f32p))
+    return float(r[0]) if env.N == 1 else r
+
+
+@is_terminal.register(HipVecEnv)
+def _(env):
+    d = np.empty(env.N, np.uint8)
+    call("ppo_env_get_terminal", env._h, _p(d, _lib.c_u8p))
+    return bool(d[0]) if env.N == 1 else d.astype(bool)
+
+
+@reset_.register(HipVecEnv)
+def _(env):
+    call("ppo_env_reset", env._h)
+
+
+@step_.register(HipVecEnv)
+def _(env, action):
+    a = np.atleast_1d(np.asarray(action, np.int64))
+    if a.size != env.N:
+        raise PPOError(-1, "AssertionError: step! expects one action per env")
+    if np.any(a < 1) or np.any(a > env.A):
+        raise PPOError(-1, "AssertionError: Expected 0 < action_index <= %d" % env.A)   # quad_game_utilities.jl:178
+    a0 = (a - 1).astype(np.int32)
+    call("ppo_env_step", env._h, _p(a0, _lib.c_i32p))
+
+
+# ------------------------------------------------------------------ policy
+class HipPolicy:
+    """SimplePolicy.Policy(in_channels, hidden_channels, num_hidden_layers, num_output) (test/policy.jl:9-19)
+    with parameters resident on the GPU.  `params` is the flat Flux.params vector (W [out,in] column-major)."""
+
+    def __init__(self, in_channels, hidden_channels, num_hidden_layers, num_output, seed=0):
+        h = C.c_void_p()
+        call("ppo_policy_create", int(in_channels), int(hidden_channels), int(num_hidden_layers), int(num_output),
+             C.byref(h))
+        self._h = h
+        self.in_channels, self.hidden_channels = in_channels, hidden_channels
+        self.num_hidden_layers, self.num_output = num_hidden_layers, num_output
+        n = C.c_int64(0)
+        call("ppo_policy_num_params", h, C.byref(n))
+        self.num_params = n.value
+        self.params = glorot_uniform_params(in_channels, hidden_channels, num_hidden_layers, num_output, seed)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().ppo_policy_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def params(self):
+        out = np.empty(self.num_params, np.float32)
+        call("ppo_policy_get_params", self._h, _p(out, _lib.c_f32p))
+        return out
+
+    @params.setter
+    def params(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        if flat.size != self.num_params:
+            raise PPOError(-1, "AssertionError: expected %d parameters, got %d" % (self.num_params, flat.size))
+        call("ppo_policy_set_params", self._h, _p(flat, _lib.c_f32p))
+
+    def grad(self):
+        out = np.empty(self.num_params, np.float32)
+        call("ppo_policy_get_grad", self._h, _p(out, _lib.c_f32p))
+        return out
+
+    def grad_buffer_dev(self):
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        call("ppo_policy_grad_buffer_dev", self._h, C.byref(ptr), C.byref(n))
+        return ptr.value, n.value
+
+    def layer_shapes(self):
+        d = [(self.hidden_channels, self.in_channels)] + [(self.hidden_channels, self.hidden_channels)] * \
+            (self.num_hidden_layers - 1) + [(self.num_output, self.hidden_channels)]
+        return d
+
+
+def glorot_uniform_params(F, HID, n_hidden, out, seed=0):
+    """Flux default init: Glorot-uniform weights, zero bias; flat Flux order."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for (o, i) in [(HID, F)] + [(HID, HID)] * (n_hidden - 1) + [(out, HID)]:
+        lim = np.sqrt(6.0 / (o + i))
+        W = rng.uniform(-lim, lim, size=(o, i)).astype(np.float32)
+        parts += [W.ravel(order="F"), np.zeros(o, np.float32)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def _forward(policy, vs, bits):
+    vs = np.ascontiguousarray(vs, np.int8)
+    bits = np.ascontiguousarray(bits, np.uint32)
+    B, Hh, F = vs.shape
+    probs = np.empty((B, Hh * 4), np.float32)
+    call("ppo_policy_forward", policy._h, _p(vs, _lib.c_i8p), _p(bits, _lib.c_u32p), B, Hh, _p(probs, _lib.c_f32p))
+    return probs
+
+
+@action_probabilities.register(HipPolicy)
+def _(policy, s):
+    """test/quad_game_utilities.jl:65-71 -> vector of length A."""
+    return _forward(policy, np.asarray(s.vertex_score)[None], np.atleast_1d(np.uint32(s.action_mask)))[0]
+
+
+@batch_action_probabilities.register(HipPolicy)
+def _(policy, s):
+    """test/quad_game_utilities.jl:73-79 -> [A,B] (returned as the transposed view of the C-order [B,A])."""
+    return _forward(policy, s.vertex_score, s.action_mask).T
+
+
+# ------------------------------------------------------------------ optimiser
+class Adam:
+    """Flux legacy Adam(eta, beta, epsilon)."""
+
+    def __init__(self, eta=1e-3, beta=(0.9, 0.999), epsilon=1e-8):
+        self.eta, self.beta, self.epsilon = float(eta), (float(beta[0]), float(beta[1])), float(epsilon)
+        self._h = None
+        self._policy = None
+
+    def _bind(self, policy):
+        if self._h is None:
+            h = C.c_void_p()
+            call("ppo_adam_create", policy._h, self.eta, self.beta[0], self.beta[1], self.epsilon, C.byref(h))
+            self._h, self._policy = h, policy
+        elif self._policy is not policy:
+            raise PPOError(-1, "AssertionError: optimiser state belongs to another policy")
+        call("ppo_adam_set_lr", self._h, float(self.eta))
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ppo_adam_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def get_state(self):
+        n = self._policy.num_params
+        m, v, bp = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(2, np.float64)
+        call("ppo_adam_get_state", self._h, _p(m, _lib.c_f32p), _p(v, _lib.c_f32p), _p(bp, _lib.c_f64p))
+        return m, v, bp
+
+
+class Optimiser:
+    """Flux.Optimiser(...): iterable composite (get_optimizer_learning_rate iterates it, src/train.jl:155-158)."""
+
+    def __init__(self, *members):
+        self.members = list(members)
+
+    def __iter__(self):
+        return iter(self.members)
+
+    def _adam(self):
+        adams = [m for m in self.members if isinstance(m, Adam)]
+        if len(adams) != 1 or len(self.members) != 1:
+            raise PPOError(-4, "only Optimiser(Adam(...)) is implemented on the device")
+        return adams[0]
+
+
+def get_optimizer_learning_rate(optimizer):
+    lr = 1.0
+    for opt in optimizer:          # a bare Adam is not iterable, like the reference
+        lr *= opt.eta
+    return lr
+
+
+# ------------------------------------------------------------------ standalone ops
+def compute_returns(rewards, terminal, discount):
+    """src/collect_rollouts.jl:26-42.  A Python float discount is a Float64 (running value in fp64);
+    pass np.float32(discount) for the all-Float32 variant."""
+    r = np.ascontiguousarray(rewards, np.float32)
+    t = np.ascontiguousarray(terminal, np.uint8)
+    if r.shape != t.shape:
+        raise PPOError(-1, "AssertionError: rewards and terminal differ in length")
+    out = np.empty_like(r)
+    call("ppo_compute_returns", _p(r, _lib.c_f32p), _p(t, _lib.c_u8p), r.size, float(discount),
+         int(isinstance(discount, np.float32)), _p(out, _lib.c_f32p))
+    return out
+
+
+def compute_returns_tn(rewards, done, discount):
+    r = np.ascontiguousarray(rewards, np.float32)
+    d = np.ascontiguousarray(done, np.uint8)
+    T, N = r.shape
+    out = np.empty_like(r)
+    call("ppo_compute_returns_tn", _p(r, _lib.c_f32p), _p(d, _lib.c_u8p), T, N, float(discount),
+         int(isinstance(discount, np.float32)), _p(out, _lib.c_f32p))
+    return out
+
+
+def gae_tn(rewards, done, values, gamma, lam):
+    r = np.ascontiguousarray(rewards, np.float32)
+    d = np.ascontiguousarray(done, np.uint8)
+    v = np.ascontiguousarray(values, np.float32)
+    T, N = r.shape
+    adv, ret = np.empty_like(r), np.empty_like(r)
+    call("ppo_gae_tn", _p(r, _lib.c_f32p), _p(d, _lib.c_u8p), _p(v, _lib.c_f32p), T, N, float(gamma), float(lam),
+         _p(adv, _lib.c_f32p), _p(ret, _lib.c_f32p))
+    return adv, ret
+
+
+def categorical_sample(probs, u):
+    """rand(Categorical(p)) for rows of probs [B,A] with uniforms u[B]; returns 1-based actions,
+    selected probabilities and the ap[a] > 0 assertion flags (src/collect_rollouts.jl:6-7)."""
+    p = np.ascontiguousarray(probs, np.float32)
+    uu = np.ascontiguousarray(u, np.float32)
+    B, A = p.shape
+    a, ps, err = np.empty(B, np.int32), np.empty(B, np.float32), np.empty(B, np.int32)
+    call("ppo_categorical_sample", _p(p, _lib.c_f32p), _p(uu, _lib.c_f32p), B, A, _p(a, _lib.c_i32p),
+         _p(ps, _lib.c_f32p), _p(err, _lib.c_i32p))
+    return a.astype(np.int64) + 1, ps, err
+
+
+def simplified_ppo_clip(advantage, epsilon):
+    """src/train.jl:1-7 (scalar helper; the device path fuses it into the loss kernel)."""
+    return (1.0 + epsilon) * advantage if advantage >= 0 else (1.0 - epsilon) * advantage
+
+
+def get_linear_action_index(selected_actions, num_actions_per_state):
+    """src/train.jl:48-52 (1-based in, 1-based out)."""
+    a = np.ascontiguousarray(selected_actions, np.int64)
+    out = np.empty_like(a)
+    call("ppo_linear_action_index", _p(a, _lib.c_i64p), a.size, int(num_actions_per_state), _p(out, _lib.c_i64p))
+    return out
+
+
+def ppo_loss_with_entropy(probs_AB, linear_action_index, old_action_probabilities, advantage, epsilon):
+    """Forward-only loss on given probabilities [A,B] (src/train.jl:35-46) -> (ppoloss, entropyloss)."""
+    pr = np.ascontiguousarray(np.asarray(probs_AB, np.float32).T)          # [B,A] C-order == [A,B] column-major
+    B, A = pr.shape
+    li = np.ascontiguousarray(linear_action_index, np.int64)
+    po = np.ascontiguousarray(old_action_probabilities, np.float32)
+    ad = np.ascontiguousarray(advantage, np.float32)
+    a, b = C.c_double(0), C.c_double(0)
+    call("ppo_loss_with_entropy", _p(pr, _lib.c_f32p), _p(li, _lib.c_i64p), _p(po, _lib.c_f32p), _p(ad, _lib.c_f32p),
+         B, A, float(epsilon), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def philox4x32_10(ctr, key):
+    c = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4)
+    k = np.ascontiguousarray(key, np.uint32)
+    out = np.empty_like(c)
+    call("ppo_philox4x32_10", _p(c, _lib.c_u32p), _p(k, _lib.c_u32p), c.shape[0], _p(out, _lib.c_u32p))
+    return out
+
+
+# ------------------------------------------------------------------ rollouts / dataset
+class BufferRollouts:
+    """PPO.BufferRollouts() (src/rollout_buffer.jl:1-22): device-resident SoA columns [T,N]."""
+
+    def __init__(self):
+        self._h = None
+        self._env = None
+
+    def _ensure(self, env, T):
+        if self._h is None:
+            h = C.c_void_p()
+            call("ppo_rollouts_create", env._h, int(T), C.byref(h))
+            self._h, self._env = h, env
+        return self._h
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ppo_rollouts_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __len__(self):                                     # Base.length (src/rollout_buffer.jl:40-48)
+        if self._h is None:
+            return 0
+        n = C.c_int64(0)
+        call("ppo_rollouts_len", self._h, C.byref(n))
+        return n.value
+
+    def dims(self):
+        T, N = C.c_int64(0), C.c_int64(0)
+        call("ppo_rollouts_dims", self._h, C.byref(T), C.byref(N))
+        return T.value, N.value
+
+    def _get(self, fn, dtype, ctype, extra=()):
+        T, N = self.dims()
+        out = np.empty((T, N) + tuple(extra), dtype)
+        call(fn, self._h, _p(out, ctype))
+        return out
+
+    # columns (time-major [T,N]); names follow the reference struct fields
+    @property
+    def selected_actions(self):
+        return self._get("ppo_rollouts_get_actions", np.int32, _lib.c_i32p).astype(np.int64) + 1
+
+    @property
+    def selected_action_probabilities(self):
+        return self._get("ppo_rollouts_get_probs", np.float32, _lib.c_f32p)
+
+    @property
+    def rewards(self):
+        """After collect_rollouts! this column holds the RETURNS (compute_state_value! overwrites it,
+        src/rollout_buffer.jl:55-64)."""
+        return self._get("ppo_rollouts_get_returns", np.float32, _lib.c_f32p)
+
+    @property
+    def raw_rewards(self):
+        return self._get("ppo_rollouts_get_raw_rewards", np.float32, _lib.c_f32p)
+
+    @property
+    def terminal(self):
+        return self._get("ppo_rollouts_get_terminal", np.uint8, _lib.c_u8p).astype(bool)
+
+    @property
+    def valid(self):
+        return self._get("ppo_rollouts_get_valid", np.uint8, _lib.c_u8p).astype(bool)
+
+    @property
+    def state_data(self):
+        T, N = self.dims()
+        env = self._env
+        st = np.empty((T, N, env.H, env.F), np.int8)
+        act = np.empty((T, N), np.uint32)
+        call("ppo_rollouts_get_states", self._h, _p(st, _lib.c_i8p), _p(act, _lib.c_u32p))
+        return st, act
+
+    def full_probs(self):
+        T, N = self.dims()
+        out = np.empty((T, N, self._env.A), np.float32)
+        call("ppo_rollouts_get_full_probs", self._h, _p(out, _lib.c_f32p))
+        return out
+
+    def index(self):
+        """Dataset order: flat transition ids t*N+n of the valid transitions."""
+        idx = np.empty(len(self), np.int64)
+        call("ppo_rollouts_get_index", self._h, _p(idx, _lib.c_i64p))
+        return idx
+
+    def set_columns(self, env, states, active, actions1, p_sel, returns, terminal=None):
+        """Load columns from the host (generic host-side envs, tests)."""
+        st = np.ascontiguousarray(states, np.int8)
+        T = st.shape[0]
+        self._ensure(env, T)
+        ac = np.ascontiguousarray(active, np.uint32)
+        a0 = np.ascontiguousarray(np.asarray(actions1, np.int64) - 1, np.int32)
+        ps = np.ascontiguousarray(p_sel, np.float32)
+        rt = np.ascontiguousarray(returns, np.float32)
+        tm = None if terminal is None else np.ascontiguousarray(terminal, np.uint8)
+        call("ppo_rollouts_set", self._h, T, _p(st, _lib.c_i8p), _p(ac, _lib.c_u32p), _p(a0, _lib.c_i32p),
+             _p(ps, _lib.c_f32p), _p(rt, _lib.c_f32p), _p(tm, _lib.c_u8p) if tm is not None else None)
+
+
+def _discount_args(discount):
+    return float(discount), int(isinstance(discount, np.float32))
+
+
+def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
+    """PPO.collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79).
+    The N resident envs each play ceil(num_episodes / N) whole episodes (reset! before each)."""
+    if not isinstance(env, HipVecEnv) or not isinstance(policy, HipPolicy):
+        _not_implemented("state")
+    if num_episodes < 1:
+        raise PPOError(-1, "AssertionError: num_episodes must be >= 1")
+    per_env = -(-int(num_episodes) // env.N)
+    h = rollouts._ensure(env, per_env * env.max_actions)
+    g, f32 = _discount_args(discount)
+    call("ppo_collect_rollouts_episodes", h, env._h, policy._h, per_env, g, f32)
+
+
+def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False):
+    """Vectorised fixed-T form: num_steps steps of all N envs with auto-reset (the throughput path)."""
+    h = rollouts._ensure(env, int(num_steps))
+    g, f32 = _discount_args(discount)
+    call("ppo_collect_rollouts", h, env._h, policy._h, int(num_steps), g, f32, int(bool(record_probs)))
+
+
+class BufferDataset:
+    """src/rollout_buffer.jl:95-147.  Non-owning view; indices are 1-based like the reference."""
+
+    def __init__(self, rollouts):
+        self.rollouts = rollouts
+        self._cache = None
+
+    def __len__(self):
+        return len(self.rollouts)
+
+    def _columns(self):
+        if self._cache is None:
+            r = self.rollouts
+            st, act = r.state_data
+            idx = r.index()
+            self._cache = dict(idx=idx, st=st.reshape(-1, st.shape[2], st.shape[3]), act=act.reshape(-1),
+                               a=r.selected_actions.reshape(-1), p=r.selected_action_probabilities.reshape(-1),
+                               ret=r.rewards.reshape(-1))
+        return self._cache
+
+    def __getitem__(self, idx):
+        c = self._columns()
+        n = len(self)
+        if isinstance(idx, (int, np.integer)):
+            if not (1 <= idx <= n):
+                raise PPOError(-1, "AssertionError: 1 <= idx <= length(rollouts)")         # :105-106
+            t = c["idx"][idx - 1]
+            return {"state": StateData(c["st"][t], c["act"][t]), "selected_action": int(c["a"][t]),
+                    "selected_action_probability": float(c["p"][t]), "returns": float(c["ret"][t])}
+        if isinstance(idx, (list, tuple, np.ndarray)):
+            ii = np.asarray(idx, np.int64)
+            if ii.size and (ii.min() < 1 or ii.max() > n):
+                raise PPOError(-1, "AssertionError: dataset index out of range")
+            t = c["idx"][ii - 1]
+            return {"state": StateData(c["st"][t], c["act"][t]), "selected_action": c["a"][t],
+                    "selected_action_probability": c["p"][t], "returns": c["ret"][t]}
+        raise PPOError(-1, "Dataset index should be Int or Array, got %s" % type(idx).__name__)   # :141
+
+
+def construct_dataset(rollouts):
+    return BufferDataset(rollouts)
+
+
+# ------------------------------------------------------------------ training
+def step_batch_(policy, optimizer, dataset, batch_indices, epsilon, entropy_weight):
+    """One optimiser step on dataset[batch_indices] (1-based): gather + batch_advantage (=returns) +
+    get_linear_action_index + step_batch! (src/train.jl:98-120, 54-84).  Returns (ppoloss, entropy_weight*entropyloss)."""
+    adam = optimizer._adam()
+    oh = adam._bind(policy)
+    ii = np.ascontiguousarray(np.asarray(batch_indices, np.int64) - 1)
+    a, b = C.c_double(0), C.c_double(0)
+    call("ppo_step_batch", policy._h, oh, dataset.rollouts._h, _p(ii, _lib.c_i64p), ii.size, float(epsilon),
+         float(entropy_weight), 0, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def forward_backward(policy, dataset, batch_indices, epsilon, entropy_weight, B_global=None):
+    """Gradient only (no update): leaves the flat gradient in policy.grad(); returns the two losses."""
+    ii = np.ascontiguousarray(np.asarray(batch_indices, np.int64) - 1)
+    call("ppo_forward_backward", policy._h, dataset.rollouts._h, _p(ii, _lib.c_i64p), ii.size,
+         int(B_global or ii.size), float(epsilon), float(entropy_weight), 0)
+    a, b = C.c_double(0), C.c_double(0)
+    call("ppo_last_losses", policy._h, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight, perm=None, seed=0,
+               parallel=None, verbose=True):
+    """PPO.ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight)
+    (src/train.jl:130-153) -> (ppo_loss_history, entropy_loss_history, lr_history).
+    perm: optional [num_epochs, len] 1-based permutations standing in for randperm (:93)."""
+    adam = optimizer._adam()
+    oh = adam._bind(policy)
+    n = len(dataset)
+    if not (1 <= batch_size <= n):
+        raise PPOError(-1, "AssertionError: 1 <= batch_size <= num_data")                    # :88
+    pp = None
+    if perm is not None:
+        pp = np.ascontiguousarray(np.asarray(perm, np.int64).reshape(num_epochs, n) - 1)
+    ph, eh, lh = (np.zeros(num_epochs, np.float64) for _ in range(3))
+    world, fn, keep = 1, _lib.ALLREDUCE_FN(0), None
+    if parallel is not None and parallel.world > 1:
+        world = parallel.world
+        keep = parallel.make_hook(policy)
+        fn = keep
+    call("ppo_train", policy._h, oh, dataset.rollouts._h, float(epsilon), int(batch_size), int(num_epochs),
+         float(entropy_weight), 0, _p(pp, _lib.c_i64p) if pp is not None else None, int(seed), int(world), fn, None,
+         _p(ph, _lib.c_f64p), _p(eh, _lib.c_f64p), _p(lh, _lib.c_f64p))
+    lr = get_optimizer_learning_rate(optimizer)
+    if verbose:
+        for e in range(num_epochs):                                                         # :146
+            print("EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e" % (e + 1, ph[e], eh[e], lr))
+    return list(ph), list(eh), [lr] * num_epochs
+
+
+def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size, num_ppo_iterations, evaluator,
+                 epochs_per_iteration, discount, epsilon, entropy_weight, verbose=True):
+    """PPO.ppo_iterate! in-memory method (src/train.jl:210-249), positional argument order preserved."""
+    loss = {"ppo": [], "entropy": [], "lr": []}
+    for it in range(1, num_ppo_iterations + 1):
+        evaluator(policy, env, optimizer)                                                    # :226
+        if verbose:
+            print("\nPPO ITERATION : %d" % it)
+        rollouts = BufferRollouts()                                                          # :230
+        collect_rollouts_(rollouts, env, policy, episodes_per_iteration, discount)
+        dataset = construct_dataset(rollouts)
+        p, e, lr = ppo_train_(policy, optimizer, dataset, epsilon, minibatch_size, epochs_per_iteration,
+                              entropy_weight, verbose=verbose)
+        loss["ppo"] += p
+        loss["entropy"] += e
+        loss["lr"] += lr
+        try:
+            save_loss(evaluator, loss)                                                       # :247
+        except PPOError:
+            pass                         # no save_loss method exists anywhere in the reference (Appendix B)
+    return loss
+
+
+# ------------------------------------------------------------------ data parallel (one process per GPU)
+class _DevArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+class DataParallel:
+    """Env shards are data-parallel across ranks; the only exchange is one all-reduce (sum) of the flat
+    gradient buffer [num_params + 2] per optimiser step, through torch.distributed (backend "nccl" = RCCL
+    over xGMI on MI355X; "gloo" for the CPU rehearsal of the host logic)."""
+
+    def __init__(self, rank=0, world=1):
+        self.rank, self.world = int(rank), int(world)
+
+    def env_shard(self, total_envs):
+        """Contiguous shard [offset, offset+n) of this rank; RNG uses global env ids."""
+        base, rem = divmod(int(total_envs), self.world)
+        n = base + (1 if self.rank < rem else 0)
+        off = self.rank * base + min(self.rank, rem)
+        return off, n
+
+    @staticmethod
+    def allreduce_(tensor):
+        import torch.distributed as dist
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        return tensor
+
+    def make_hook(self, policy):
+        import torch
+        ptr, n = policy.grad_buffer_dev()
+        t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+
+        def hook(ctx, dev_ptr, n_floats):
+            try:
+                self.allreduce_(t)
+                return 0
+            except Exception:
+                return 1
+        return _lib.ALLREDUCE_FN(hook)

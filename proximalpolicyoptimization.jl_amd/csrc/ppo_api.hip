@@ -1,0 +1,686 @@
+// ppo_api.hip -- extern "C" surface of libppo_hip.so (include/ppo_hip.h): handle management and
+// the host-side orchestration of collect_rollouts! / ppo_train! (launch order only; all math is
+// in the kernels).  There is NO CPU fallback: every entry point runs on the GPU or fails.
+#include "ppo_internal.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+int32_t launch_loss_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);
+
+// ---------------------------------------------------------------- globals
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static bool g_own_stream = false;
+static bool g_init = false;
+static bool g_prof = false;
+struct ProfRec { hipEvent_t e0, e1; };
+static std::map<std::string, std::vector<ProfRec>> g_prof_pending;
+static std::map<std::string, std::pair<double, int64_t>> g_prof_done;
+
+void ppo_set_error(const std::string& msg) { g_err = msg; }
+hipStream_t ppo_stream() { return g_stream; }
+int ppo_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
+    return PPO_ERR_HIP;
+}
+
+ProfScope::ProfScope(const char* n) : name(n), e0(nullptr), e1(nullptr), on(g_prof) {
+    if (on) {
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, g_stream);
+    }
+}
+ProfScope::~ProfScope() {
+    if (on) {
+        (void)hipEventRecord(e1, g_stream);
+        g_prof_pending[name].push_back({e0, e1});
+    }
+}
+
+static int32_t ensure_init() {
+    if (g_init) return PPO_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        ppo_set_error("no HIP device available: libppo_hip has no CPU fallback");
+        return PPO_ERR_HIP;
+    }
+    HIP_TRY(hipStreamCreate(&g_stream));
+    g_own_stream = true;
+    g_init = true;
+    return PPO_OK;
+}
+
+template <typename T>
+static int32_t h2d(T* dst, const T* src, size_t n) {
+    if (n == 0) return PPO_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PPO_OK;
+}
+template <typename T>
+static int32_t d2h(T* dst, const T* src, size_t n) {
+    if (n == 0) return PPO_OK;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PPO_OK;
+}
+
+extern "C" {
+
+int32_t ppo_version(void) { return 100; }
+
+int32_t ppo_last_error(char* buf, int64_t cap) {
+    if (!buf || cap <= 0) return PPO_ERR_ARG;
+    std::strncpy(buf, g_err.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return PPO_OK;
+}
+
+int32_t ppo_device_count(int32_t* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (out) *out = n;
+    return PPO_OK;
+}
+
+int32_t ppo_device_init(int32_t device_ordinal) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { ppo_set_error("no HIP device available: libppo_hip has no CPU fallback"); return PPO_ERR_HIP; }
+    ARG_CHECK(device_ordinal >= 0 && device_ordinal < n, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    if (!g_init) {
+        HIP_TRY(hipStreamCreate(&g_stream));
+        g_own_stream = true;
+        g_init = true;
+    }
+    return PPO_OK;
+}
+
+int32_t ppo_set_stream(void* hip_stream) {
+    PPO_TRY(ensure_init());
+    if (g_own_stream && g_stream) { (void)hipStreamSynchronize(g_stream); (void)hipStreamDestroy(g_stream); }
+    g_stream = (hipStream_t)hip_stream;
+    g_own_stream = false;
+    return PPO_OK;
+}
+
+int32_t ppo_device_synchronize(void) {
+    PPO_TRY(ensure_init());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PPO_OK;
+}
+
+int32_t ppo_profile_enable(int32_t on) {
+    g_prof = on != 0;
+    if (on) { g_prof_pending.clear(); g_prof_done.clear(); }
+    return PPO_OK;
+}
+
+int32_t ppo_profile_get(const char* kernel_name, double* total_ms, int64_t* launches) {
+    PPO_TRY(ensure_init());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    for (auto& kv : g_prof_pending) {
+        auto& acc = g_prof_done[kv.first];
+        for (auto& r : kv.second) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { acc.first += ms; acc.second += 1; }
+            (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+        }
+        kv.second.clear();
+    }
+    auto it = g_prof_done.find(kernel_name ? kernel_name : "");
+    if (total_ms) *total_ms = it == g_prof_done.end() ? 0.0 : it->second.first;
+    if (launches) *launches = it == g_prof_done.end() ? 0 : it->second.second;
+    return PPO_OK;
+}
+
+// ================================================================ standalone ops
+int32_t ppo_compute_returns(const float* rewards, const uint8_t* terminal, int64_t n, double discount,
+                            int32_t discount_is_f32, float* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(n >= 0 && (n == 0 || (rewards && terminal && out)), "compute_returns: null buffer");
+    if (n == 0) return PPO_OK;
+    DevBuf<float> r, o; DevBuf<uint8_t> t;
+    PPO_TRY(r.alloc(n)); PPO_TRY(o.alloc(n)); PPO_TRY(t.alloc(n));
+    PPO_TRY(h2d(r.p, rewards, n)); PPO_TRY(h2d(t.p, terminal, n));
+    PPO_TRY(launch_returns_flat(r.p, t.p, o.p, n, discount, discount_is_f32));
+    return d2h(out, o.p, n);
+}
+
+int32_t ppo_compute_returns_tn(const float* rewards, const uint8_t* done, int64_t T, int64_t N, double discount,
+                               int32_t discount_is_f32, float* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(T >= 0 && N >= 0, "compute_returns_tn: negative size");
+    const size_t n = (size_t)T * N;
+    if (n == 0) return PPO_OK;
+    ARG_CHECK(rewards && done && out, "compute_returns_tn: null buffer");
+    DevBuf<float> r, o; DevBuf<uint8_t> t;
+    PPO_TRY(r.alloc(n)); PPO_TRY(o.alloc(n)); PPO_TRY(t.alloc(n));
+    PPO_TRY(h2d(r.p, rewards, n)); PPO_TRY(h2d(t.p, done, n));
+    PPO_TRY(launch_returns_tn(r.p, t.p, o.p, T, N, discount, discount_is_f32));
+    return d2h(out, o.p, n);
+}
+
+int32_t ppo_gae_tn(const float* rewards, const uint8_t* done, const float* values, int64_t T, int64_t N, double gamma,
+                   double lambda, float* adv_out, float* ret_out) {
+    PPO_TRY(ensure_init());
+    const size_t n = (size_t)T * N;
+    if (n == 0) return PPO_OK;
+    ARG_CHECK(rewards && done && values && adv_out && ret_out, "gae_tn: null buffer");
+    DevBuf<float> r, v, a, o; DevBuf<uint8_t> t;
+    PPO_TRY(r.alloc(n)); PPO_TRY(v.alloc(n + N)); PPO_TRY(a.alloc(n)); PPO_TRY(o.alloc(n)); PPO_TRY(t.alloc(n));
+    PPO_TRY(h2d(r.p, rewards, n)); PPO_TRY(h2d(t.p, done, n)); PPO_TRY(h2d(v.p, values, n + N));
+    PPO_TRY(launch_gae_tn(r.p, t.p, v.p, a.p, o.p, T, N, gamma, lambda));
+    PPO_TRY(d2h(adv_out, a.p, n));
+    return d2h(ret_out, o.p, n);
+}
+
+int32_t ppo_categorical_sample(const float* probs, const float* u, int64_t B, int64_t A, int32_t* actions,
+                               float* p_sel, int32_t* err) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(B >= 0 && A >= 1, "categorical_sample: bad shape");
+    if (B == 0) return PPO_OK;
+    DevBuf<float> p, uu, ps; DevBuf<int32_t> ac, er;
+    PPO_TRY(p.alloc((size_t)B * A)); PPO_TRY(uu.alloc(B)); PPO_TRY(ps.alloc(B)); PPO_TRY(ac.alloc(B)); PPO_TRY(er.alloc(B));
+    PPO_TRY(h2d(p.p, probs, (size_t)B * A)); PPO_TRY(h2d(uu.p, u, B));
+    PPO_TRY(launch_categorical(p.p, uu.p, B, A, ac.p, ps.p, er.p));
+    PPO_TRY(d2h(actions, ac.p, B)); PPO_TRY(d2h(p_sel, ps.p, B));
+    return d2h(err, er.p, B);
+}
+
+int32_t ppo_linear_action_index(const int64_t* actions1, int64_t B, int64_t A, int64_t* out) {
+    // src/train.jl:48-52: selected_actions + range(0, step=A, length=B).  Pure index arithmetic on
+    // the host side of the ABI (it is fused into the loss kernel on the device path).
+    ARG_CHECK(B >= 0 && A >= 1, "linear_action_index: bad shape");
+    for (int64_t b = 0; b < B; ++b) out[b] = actions1[b] + b * A;
+    return PPO_OK;
+}
+
+// ================================================================ env
+int32_t ppo_env_create(int32_t kind, int64_t num_envs, int64_t global_env_offset, int32_t Q, int32_t max_actions,
+                       float no_action_reward, uint64_t seed, ppo_env_t* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(out, "env_create: null out");
+    ARG_CHECK(kind == 0, "env_create: only kind 0 (synthetic rand-poly-shaped env) is built in");
+    ARG_CHECK(num_envs >= 1 && Q >= 2 && Q <= 32 && max_actions >= 1, "env_create: bad sizes");
+    ppo_env_s* e = new ppo_env_s();
+    e->kind = kind; e->Q = Q; e->H = 4 * Q; e->A = 16 * Q; e->V = 4 * Q; e->F = 2 * PPO_TPL;
+    e->max_actions = max_actions; e->no_action_reward = no_action_reward; e->N = num_envs;
+    e->global_offset = global_env_offset; e->seed = seed;
+    const size_t N = (size_t)num_envs;
+    int32_t s = PPO_OK;
+    if ((s = e->score.alloc(N * e->V)) || (s = e->degree.alloc(N * e->V)) || (s = e->active.alloc(N)) ||
+        (s = e->steps.alloc(N)) || (s = e->reward.alloc(N)) || (s = e->done.alloc(N)) || (s = e->episode.alloc(N)) ||
+        (s = e->tick.alloc(N)) || (s = e->err.alloc(1)) || (s = e->actions_tmp.alloc(N)) ||
+        (s = e->episodes_left.alloc(N))) { delete e; return s; }
+    (void)hipMemsetAsync(e->episode.p, 0, N * 4, g_stream);
+    (void)hipMemsetAsync(e->tick.p, 0, N * 4, g_stream);
+    (void)hipMemsetAsync(e->err.p, 0, 4, g_stream);
+    (void)hipMemsetAsync(e->done.p, 0, N, g_stream);
+    (void)hipMemsetAsync(e->episodes_left.p, 0, N * 4, g_stream);
+    s = launch_env_reset(e, 0);
+    if (s) { delete e; return s; }
+    *out = e;
+    return PPO_OK;
+}
+
+int32_t ppo_env_destroy(ppo_env_t env) { if (env) { (void)hipStreamSynchronize(g_stream); delete env; } return PPO_OK; }
+
+int32_t ppo_env_dims(ppo_env_t env, int64_t* N, int32_t* H, int32_t* F, int32_t* A) {
+    ARG_CHECK(env, "env_dims: null env");
+    if (N) *N = env->N; if (H) *H = env->H; if (F) *F = env->F; if (A) *A = env->A;
+    return PPO_OK;
+}
+
+int32_t ppo_env_reset(ppo_env_t env) { ARG_CHECK(env, "reset!: null env"); return launch_env_reset(env, 0); }
+
+int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null) {
+    ARG_CHECK(env, "null env");
+    int32_t f = 0;
+    PPO_TRY(d2h(&f, env->err.p, 1));
+    if (flags_or_null) *flags_or_null = f;
+    if (f) {
+        std::string m = "AssertionError (device flag):";
+        if (f & 1) m += " action on inactive quad;";
+        if (f & 2) m += " action index out of range;";
+        if (f & 4) m += " step! on a terminated env;";
+        if (f & 8) m += " sampled action has probability 0 (ap[a] > 0.0 failed, src/collect_rollouts.jl:7);";
+        ppo_set_error(m);
+        return PPO_ERR_DEVICE_FLAG;
+    }
+    return PPO_OK;
+}
+
+int32_t ppo_env_step(ppo_env_t env, const int32_t* actions0) {
+    ARG_CHECK(env && actions0, "step!: null argument");
+    PPO_TRY(h2d(env->actions_tmp.p, actions0, (size_t)env->N));
+    PPO_TRY(launch_env_step(env, env->actions_tmp.p, nullptr, nullptr, nullptr, 0, 0));
+    return ppo_env_check_errors(env, nullptr);
+}
+
+int32_t ppo_env_get_state(ppo_env_t env, int8_t* obs, uint32_t* active) {
+    ARG_CHECK(env && obs, "state: null argument");
+    const size_t n = (size_t)env->N * env->H * env->F;
+    PPO_TRY(env->obs_tmp.alloc(n));
+    PPO_TRY(launch_env_observe(env, env->obs_tmp.p, nullptr));
+    PPO_TRY(d2h(obs, env->obs_tmp.p, n));
+    if (active) PPO_TRY(d2h(active, env->active.p, (size_t)env->N));
+    return PPO_OK;
+}
+
+int32_t ppo_env_get_reward(ppo_env_t env, float* out) { ARG_CHECK(env && out, "reward: null"); return d2h(out, env->reward.p, (size_t)env->N); }
+int32_t ppo_env_get_terminal(ppo_env_t env, uint8_t* out) { ARG_CHECK(env && out, "is_terminal: null"); return d2h(out, env->done.p, (size_t)env->N); }
+
+int32_t ppo_env_get_internal(ppo_env_t env, int8_t* score, int8_t* degree, int32_t* steps, uint32_t* episode,
+                             uint32_t* tick) {
+    ARG_CHECK(env, "null env");
+    const size_t N = (size_t)env->N;
+    if (score) PPO_TRY(d2h(score, env->score.p, N * env->V));
+    if (degree) PPO_TRY(d2h(degree, env->degree.p, N * env->V));
+    if (steps) PPO_TRY(d2h(steps, env->steps.p, N));
+    if (episode) PPO_TRY(d2h(episode, env->episode.p, N));
+    if (tick) PPO_TRY(d2h(tick, env->tick.p, N));
+    return PPO_OK;
+}
+
+// ================================================================ policy
+int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers, int32_t out_per_edge,
+                          ppo_policy_t* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(out, "policy_create: null out");
+    if (num_hidden_layers != 2 || out_per_edge != PPO_OUT ||
+        !((F == 72 && (hidden == 256 || hidden == 128)) || (F == 216 && hidden == 128))) {
+        ppo_set_error("policy_create: the gfx950 kernels are built for Policy(72|216, 128|256, 2, 4) "
+                      "(test/test_square_mesh.jl:29, test/output/*.bson, BASELINE config 2)");
+        return PPO_ERR_UNSUPPORTED;
+    }
+    ppo_policy_s* p = new ppo_policy_s();
+    p->F = F; p->HID = hidden; p->L = num_hidden_layers; p->OUT = out_per_edge;
+    p->np = (int64_t)hidden * F + hidden + (int64_t)hidden * hidden + hidden + (int64_t)PPO_OUT * hidden + PPO_OUT;
+    int32_t s = PPO_OK;
+    if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F)) || (s = p->w2p.alloc((size_t)hidden * hidden)) ||
+        (s = p->w2tp.alloc((size_t)hidden * hidden)) || (s = p->b1p.alloc(hidden)) || (s = p->b2p.alloc(hidden)) ||
+        (s = p->w3p.alloc((size_t)hidden * PPO_OUT)) || (s = p->b3.alloc(PPO_OUT)) || (s = p->grad.alloc(p->np + 2)) ||
+        (s = p->err.alloc(1))) { delete p; return s; }
+    (void)hipMemsetAsync(p->params.p, 0, p->np * 4, g_stream);
+    (void)hipMemsetAsync(p->grad.p, 0, (p->np + 2) * 4, g_stream);
+    (void)hipMemsetAsync(p->err.p, 0, 4, g_stream);
+    s = launch_pack_params(p);
+    if (s) { delete p; return s; }
+    *out = p;
+    return PPO_OK;
+}
+
+int32_t ppo_policy_destroy(ppo_policy_t pol) { if (pol) { (void)hipStreamSynchronize(g_stream); delete pol; } return PPO_OK; }
+int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n) { ARG_CHECK(pol && n, "null"); *n = pol->np; return PPO_OK; }
+
+int32_t ppo_policy_set_params(ppo_policy_t pol, const float* flat) {
+    ARG_CHECK(pol && flat, "set_params: null");
+    PPO_TRY(h2d(pol->params.p, flat, (size_t)pol->np));
+    return launch_pack_params(pol);
+}
+int32_t ppo_policy_get_params(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_params: null"); return d2h(flat, pol->params.p, (size_t)pol->np); }
+int32_t ppo_policy_get_grad(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_grad: null"); return d2h(flat, pol->grad.p, (size_t)pol->np); }
+int32_t ppo_policy_grad_buffer_dev(ppo_policy_t pol, void** dev_ptr, int64_t* n_floats) {
+    ARG_CHECK(pol && dev_ptr && n_floats, "grad_buffer_dev: null");
+    *dev_ptr = pol->grad.p; *n_floats = pol->np + 2;
+    return PPO_OK;
+}
+
+int32_t ppo_policy_forward(ppo_policy_t pol, const int8_t* states, const uint32_t* active, int64_t B, int32_t H,
+                           float* probs) {
+    ARG_CHECK(pol && states && active && probs, "batch_action_probabilities: null argument");
+    ARG_CHECK(B >= 1, "batch_action_probabilities: empty batch");
+    if (H != 32) { ppo_set_error("policy_forward: H must be 32 half-edges (Q=8) in this build"); return PPO_ERR_UNSUPPORTED; }
+    DevBuf<int8_t> s; DevBuf<uint32_t> a; DevBuf<float> p;
+    const size_t ns = (size_t)B * H * pol->F;
+    PPO_TRY(s.alloc(ns)); PPO_TRY(a.alloc(B)); PPO_TRY(p.alloc((size_t)B * H * 4));
+    PPO_TRY(h2d(s.p, states, ns)); PPO_TRY(h2d(a.p, active, (size_t)B));
+    PPO_TRY(launch_policy_probs(pol, s.p, a.p, B, p.p));
+    return d2h(probs, p.p, (size_t)B * H * 4);
+}
+
+// ================================================================ optimiser
+int32_t ppo_adam_create(ppo_policy_t pol, double eta, double beta1, double beta2, double eps, ppo_adam_t* out) {
+    ARG_CHECK(pol && out, "adam_create: null");
+    ppo_adam_s* o = new ppo_adam_s();
+    o->pol = pol; o->eta = eta; o->beta1 = beta1; o->beta2 = beta2; o->eps = eps;
+    o->beta_pow[0] = beta1; o->beta_pow[1] = beta2;
+    int32_t s;
+    if ((s = o->m.alloc(pol->np)) || (s = o->v.alloc(pol->np))) { delete o; return s; }
+    (void)hipMemsetAsync(o->m.p, 0, pol->np * 4, g_stream);
+    (void)hipMemsetAsync(o->v.p, 0, pol->np * 4, g_stream);
+    *out = o;
+    return PPO_OK;
+}
+int32_t ppo_adam_destroy(ppo_adam_t opt) { if (opt) { (void)hipStreamSynchronize(g_stream); delete opt; } return PPO_OK; }
+int32_t ppo_adam_get_lr(ppo_adam_t opt, double* eta) { ARG_CHECK(opt && eta, "null"); *eta = opt->eta; return PPO_OK; }
+int32_t ppo_adam_set_lr(ppo_adam_t opt, double eta) { ARG_CHECK(opt, "null"); opt->eta = eta; return PPO_OK; }
+int32_t ppo_adam_get_state(ppo_adam_t opt, float* m, float* v, double* bp) {
+    ARG_CHECK(opt, "null");
+    if (m) PPO_TRY(d2h(m, opt->m.p, (size_t)opt->pol->np));
+    if (v) PPO_TRY(d2h(v, opt->v.p, (size_t)opt->pol->np));
+    if (bp) { bp[0] = opt->beta_pow[0]; bp[1] = opt->beta_pow[1]; }
+    return PPO_OK;
+}
+int32_t ppo_adam_set_state(ppo_adam_t opt, const float* m, const float* v, const double* bp) {
+    ARG_CHECK(opt, "null");
+    if (m) PPO_TRY(h2d(opt->m.p, m, (size_t)opt->pol->np));
+    if (v) PPO_TRY(h2d(opt->v.p, v, (size_t)opt->pol->np));
+    if (bp) { opt->beta_pow[0] = bp[0]; opt->beta_pow[1] = bp[1]; }
+    return PPO_OK;
+}
+
+// ================================================================ rollouts
+static int32_t rollouts_reserve(ppo_rollouts_s* r, int64_t T) {
+    if (T <= r->capT) return PPO_OK;
+    const size_t n = (size_t)T * r->N;
+    PPO_TRY(r->states.alloc(n * r->H * r->F)); PPO_TRY(r->active.alloc(n)); PPO_TRY(r->actions.alloc(n));
+    PPO_TRY(r->p_sel.alloc(n)); PPO_TRY(r->rewards.alloc(n)); PPO_TRY(r->returns.alloc(n)); PPO_TRY(r->done.alloc(n));
+    PPO_TRY(r->valid.alloc(n)); PPO_TRY(r->index.alloc(n));
+    r->capT = T;
+    return PPO_OK;
+}
+
+int32_t ppo_rollouts_create(ppo_env_t env, int64_t capacity_T, ppo_rollouts_t* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(env && out && capacity_T >= 0, "BufferRollouts: bad argument");
+    ppo_rollouts_s* r = new ppo_rollouts_s();
+    r->N = env->N; r->H = env->H; r->F = env->F; r->A = env->A; r->capT = 0; r->T = 0; r->len = 0;
+    int32_t s = rollouts_reserve(r, capacity_T);
+    if (s) { delete r; return s; }
+    *out = r;
+    return PPO_OK;
+}
+int32_t ppo_rollouts_destroy(ppo_rollouts_t ro) { if (ro) { (void)hipStreamSynchronize(g_stream); delete ro; } return PPO_OK; }
+int32_t ppo_rollouts_len(ppo_rollouts_t ro, int64_t* n) { ARG_CHECK(ro && n, "length: null"); *n = ro->len; return PPO_OK; }
+int32_t ppo_rollouts_dims(ppo_rollouts_t ro, int64_t* T, int64_t* N) {
+    ARG_CHECK(ro, "null"); if (T) *T = ro->T; if (N) *N = ro->N; return PPO_OK;
+}
+
+__global__ void k_iota(int32_t* p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+
+static int32_t set_index_all(ppo_rollouts_s* r) {
+    const int64_t n = r->T * r->N;
+    r->len = n; r->all_valid = true;
+    if (n == 0) return PPO_OK;
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, r->index.p, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(r->valid.p, 1, (size_t)n, g_stream));
+    return PPO_OK;
+}
+
+static int32_t check_shapes(ppo_rollouts_s* ro, ppo_env_s* env, ppo_policy_s* pol) {
+    ARG_CHECK(ro && env && pol, "collect_rollouts!: null argument");
+    ARG_CHECK(ro->N == env->N && ro->H == env->H && ro->F == env->F, "collect_rollouts!: rollouts were created for another env shape");
+    ARG_CHECK(pol->F == env->F, "collect_rollouts!: policy input width != env feature count");
+    if (env->H != 32) { ppo_set_error("collect_rollouts!: H must be 32 half-edges (Q=8) in this build"); return PPO_ERR_UNSUPPORTED; }
+    return PPO_OK;
+}
+
+int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t T, double discount,
+                             int32_t discount_is_f32, int32_t record_probs) {
+    PPO_TRY(check_shapes(ro, env, pol));
+    ARG_CHECK(T >= 1, "collect_rollouts!: T must be >= 1");
+    PPO_TRY(rollouts_reserve(ro, T));
+    const int64_t N = env->N;
+    const size_t srow = (size_t)N * env->H * env->F;
+    if (record_probs) PPO_TRY(ro->full_probs.alloc((size_t)T * N * env->A));
+    // an env left terminal by a previous call starts a fresh episode (reset! before each episode)
+    PPO_TRY(launch_env_reset(env, 1));
+    for (int64_t t = 0; t < T; ++t) {
+        int8_t* st = ro->states.p + (size_t)t * srow;
+        uint32_t* am = ro->active.p + (size_t)t * N;
+        PPO_TRY(launch_env_observe(env, st, am));                                               // state(env)
+        PPO_TRY(launch_policy_rollout(pol, env, st, am, ro->actions.p + t * N, ro->p_sel.p + t * N,
+                                      record_probs ? ro->full_probs.p + (size_t)t * N * env->A : nullptr));
+        PPO_TRY(launch_env_step(env, ro->actions.p + t * N, ro->rewards.p + t * N, ro->done.p + t * N, nullptr, 1, 0));
+    }
+    ro->T = T;
+    PPO_TRY(set_index_all(ro));
+    // compute_state_value!: returns overwrite the rewards column (src/rollout_buffer.jl:55-64)
+    PPO_TRY(launch_returns_tn(ro->rewards.p, ro->done.p, ro->returns.p, T, N, discount, discount_is_f32));
+    return ppo_env_check_errors(env, nullptr);
+}
+
+__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t episodes_per_env,
+                                      double discount, int32_t discount_is_f32) {
+    PPO_TRY(check_shapes(ro, env, pol));
+    ARG_CHECK(episodes_per_env >= 1, "collect_rollouts!: num_episodes must be >= 1");
+    const int64_t N = env->N;
+    const int64_t Tmax = episodes_per_env * env->max_actions;
+    PPO_TRY(rollouts_reserve(ro, Tmax));
+    const size_t srow = (size_t)N * env->H * env->F;
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, g_stream, env->episodes_left.p, N,
+                       (int32_t)episodes_per_env);
+    PPO_TRY(launch_env_reset(env, 0));                                  // reset!(env) before the first episode
+    std::vector<int32_t> left((size_t)N);
+    int64_t T = 0;
+    for (int64_t t = 0; t < Tmax; ++t) {
+        int8_t* st = ro->states.p + (size_t)t * srow;
+        uint32_t* am = ro->active.p + (size_t)t * N;
+        PPO_TRY(launch_env_observe(env, st, am));
+        PPO_TRY(launch_policy_rollout(pol, env, st, am, ro->actions.p + t * N, ro->p_sel.p + t * N, nullptr));
+        PPO_TRY(launch_env_step(env, ro->actions.p + t * N, ro->rewards.p + t * N, ro->done.p + t * N,
+                                ro->valid.p + t * N, 0, 1));
+        T = t + 1;
+        if ((t & 7) == 7 || t + 1 == Tmax) {            // poll completion every 8 steps
+            PPO_TRY(d2h(left.data(), env->episodes_left.p, (size_t)N));
+            bool all = true;
+            for (int64_t n = 0; n < N; ++n) if (left[n] > 0) { all = false; break; }
+            if (all) break;
+        }
+    }
+    ro->T = T;
+    // dataset order = env-major concatenation of whole episodes (the reference's flat buffer)
+    std::vector<uint8_t> valid((size_t)T * N);
+    PPO_TRY(d2h(valid.data(), ro->valid.p, (size_t)T * N));
+    std::vector<int32_t> index;
+    index.reserve((size_t)T * N);
+    for (int64_t n = 0; n < N; ++n)
+        for (int64_t t = 0; t < T; ++t)
+            if (valid[(size_t)t * N + n]) index.push_back((int32_t)(t * N + n));
+    ro->len = (int64_t)index.size();
+    ro->all_valid = false;
+    PPO_TRY(h2d(ro->index.p, index.data(), index.size()));
+    PPO_TRY(launch_returns_tn(ro->rewards.p, ro->done.p, ro->returns.p, T, N, discount, discount_is_f32));
+    return ppo_env_check_errors(env, nullptr);
+}
+
+#define RO_GETTER(name, member, type, per)                                                     \
+    int32_t name(ppo_rollouts_t ro, type* out) {                                               \
+        ARG_CHECK(ro && out, #name ": null");                                                  \
+        return d2h(out, ro->member.p, (size_t)ro->T * ro->N * (per));                          \
+    }
+RO_GETTER(ppo_rollouts_get_actions, actions, int32_t, 1)
+RO_GETTER(ppo_rollouts_get_probs, p_sel, float, 1)
+RO_GETTER(ppo_rollouts_get_returns, returns, float, 1)
+RO_GETTER(ppo_rollouts_get_raw_rewards, rewards, float, 1)
+RO_GETTER(ppo_rollouts_get_terminal, done, uint8_t, 1)
+RO_GETTER(ppo_rollouts_get_valid, valid, uint8_t, 1)
+
+int32_t ppo_rollouts_get_states(ppo_rollouts_t ro, int8_t* states, uint32_t* active) {
+    ARG_CHECK(ro, "null");
+    if (states) PPO_TRY(d2h(states, ro->states.p, (size_t)ro->T * ro->N * ro->H * ro->F));
+    if (active) PPO_TRY(d2h(active, ro->active.p, (size_t)ro->T * ro->N));
+    return PPO_OK;
+}
+int32_t ppo_rollouts_get_full_probs(ppo_rollouts_t ro, float* probs) {
+    ARG_CHECK(ro && probs, "null");
+    ARG_CHECK(ro->full_probs.p && ro->full_probs.n >= (size_t)ro->T * ro->N * ro->A, "full probabilities were not recorded");
+    return d2h(probs, ro->full_probs.p, (size_t)ro->T * ro->N * ro->A);
+}
+int32_t ppo_rollouts_get_index(ppo_rollouts_t ro, int64_t* idx) {
+    ARG_CHECK(ro && idx, "null");
+    std::vector<int32_t> tmp((size_t)ro->len);
+    PPO_TRY(d2h(tmp.data(), ro->index.p, tmp.size()));
+    for (size_t i = 0; i < tmp.size(); ++i) idx[i] = tmp[i];
+    return PPO_OK;
+}
+
+int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, const uint32_t* active,
+                         const int32_t* actions0, const float* p_sel, const float* returns, const uint8_t* terminal) {
+    ARG_CHECK(ro && T >= 1 && states && active && actions0 && p_sel && returns, "rollouts_set: bad argument");
+    PPO_TRY(rollouts_reserve(ro, T));
+    const size_t n = (size_t)T * ro->N;
+    PPO_TRY(h2d(ro->states.p, states, n * ro->H * ro->F)); PPO_TRY(h2d(ro->active.p, active, n));
+    PPO_TRY(h2d(ro->actions.p, actions0, n)); PPO_TRY(h2d(ro->p_sel.p, p_sel, n)); PPO_TRY(h2d(ro->returns.p, returns, n));
+    PPO_TRY(h2d(ro->rewards.p, returns, n));
+    if (terminal) PPO_TRY(h2d(ro->done.p, terminal, n));
+    ro->T = T;
+    return set_index_all(ro);
+}
+
+// ================================================================ training
+static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
+    if (B <= p->cap_tiles) return PPO_OK;
+    const size_t NT = p->HID / 32;
+    PPO_TRY(p->act1.alloc((size_t)B * NT * 1024)); PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
+    PPO_TRY(p->dY.alloc((size_t)B * 128)); PPO_TRY(p->loss_terms.alloc((size_t)B * 2));
+    PPO_TRY(p->slabs.alloc((size_t)256 * slab_floats(p->F, p->HID)));
+    PPO_TRY(p->idx.alloc((size_t)B));
+    p->cap_tiles = B;
+    return PPO_OK;
+}
+
+// idx_dev: transition ids (already resolved through the dataset index)
+static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
+                                    int64_t B_global, double eps, double ew) {
+    PPO_TRY(train_reserve(pol, B));
+    PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew));
+    PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
+    PPO_TRY(launch_grad_reduce(pol, B));
+    PPO_TRY(launch_loss_reduce(pol, B, B_global, ew));
+    pol->last_B = B; pol->last_entropy_weight = ew;
+    return PPO_OK;
+}
+
+__global__ void k_gather_index(const int32_t* __restrict__ index, const int64_t* __restrict__ pos, int64_t B,
+                               int64_t len, int32_t* __restrict__ out, int32_t* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t p = pos[i];
+    if (p < 0 || p >= len) { atomicOr(err, 16); out[i] = index[0]; return; }
+    out[i] = index[p];
+}
+
+int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t* sample_idx, int64_t B,
+                             int64_t B_global, double epsilon, double entropy_weight, int32_t adv_mode) {
+    ARG_CHECK(pol && ro && sample_idx, "step_batch!: null argument");
+    ARG_CHECK(B >= 1 && B <= ro->len, "step_batch!: 1 <= batch_size <= num_data (src/train.jl:88)");
+    ARG_CHECK(B_global >= B, "step_batch!: B_global < B");
+    ARG_CHECK(pol->F == ro->F && ro->H == 32, "step_batch!: shape mismatch");
+    if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
+    for (int64_t i = 0; i < B; ++i) ARG_CHECK(sample_idx[i] >= 0 && sample_idx[i] < ro->len, "dataset index out of range (src/rollout_buffer.jl:105-106)");
+    PPO_TRY(train_reserve(pol, B));
+    DevBuf<int64_t> pos;
+    PPO_TRY(pos.alloc(B));
+    PPO_TRY(h2d(pos.p, sample_idx, (size_t)B));
+    hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, g_stream, ro->index.p, pos.p, B,
+                       ro->len, pol->idx.p, pol->err.p);
+    HIP_TRY(hipGetLastError());
+    PPO_TRY(forward_backward_dev(pol, ro, pol->idx.p, B, B_global, epsilon, entropy_weight));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PPO_OK;
+}
+
+int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol) {
+    ARG_CHECK(opt && pol && opt->pol == pol, "update!: optimiser was created for another policy");
+    return launch_adam(opt);
+}
+
+int32_t ppo_last_losses(ppo_policy_t pol, double* ppoloss, double* entropyloss) {
+    ARG_CHECK(pol, "null");
+    float t[2];
+    PPO_TRY(d2h(t, pol->grad.p + pol->np, 2));
+    if (ppoloss) *ppoloss = t[0];
+    if (entropyloss) *entropyloss = t[1];
+    return PPO_OK;
+}
+
+int32_t ppo_step_batch(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, const int64_t* sample_idx, int64_t B,
+                       double epsilon, double entropy_weight, int32_t adv_mode, double* ppoloss, double* entropyloss) {
+    PPO_TRY(ppo_forward_backward(pol, ro, sample_idx, B, B, epsilon, entropy_weight, adv_mode));
+    PPO_TRY(ppo_last_losses(pol, ppoloss, entropyloss));
+    return ppo_adam_apply(opt, pol);
+}
+
+__global__ void k_perm_index(const int32_t* __restrict__ index, const int64_t* __restrict__ perm, int64_t len,
+                             int32_t* __restrict__ out, int32_t* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const int64_t p = perm[i];
+    if (p < 0 || p >= len) { atomicOr(err, 16); out[i] = index[0]; return; }
+    out[i] = index[p];
+}
+
+__global__ void k_copy_tail(const float* __restrict__ src, float* __restrict__ dst) {
+    if (threadIdx.x < 2) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon, int64_t batch_size,
+                  int32_t num_epochs, double entropy_weight, int32_t adv_mode, const int64_t* perm, uint64_t seed,
+                  int32_t world, ppo_allreduce_fn allreduce, void* allreduce_ctx, double* ppo_hist,
+                  double* entropy_hist, double* lr_hist) {
+    ARG_CHECK(pol && opt && ro && opt->pol == pol, "ppo_train!: null/mismatched argument");
+    const int64_t len = ro->len;
+    ARG_CHECK(1 <= batch_size && batch_size <= len, "1 <= batch_size <= num_data (src/train.jl:88)");
+    ARG_CHECK(num_epochs >= 0 && world >= 1, "ppo_train!: bad epochs/world");
+    ARG_CHECK(world == 1 || allreduce, "ppo_train!: world > 1 needs an all-reduce hook");
+    ARG_CHECK(pol->F == ro->F && ro->H == 32, "ppo_train!: shape mismatch");
+    if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
+    PPO_TRY(train_reserve(pol, batch_size));
+    const int64_t nb = (len + batch_size - 1) / batch_size;
+    DevBuf<int32_t> order; DevBuf<int64_t> permd; DevBuf<float> hist;
+    PPO_TRY(order.alloc(len));
+    if (perm) PPO_TRY(permd.alloc(len));
+    PPO_TRY(hist.alloc((size_t)nb * 2));
+    std::vector<float> hh((size_t)nb * 2);
+    static uint32_t epoch_counter = 0;
+    for (int32_t ep = 0; ep < num_epochs; ++ep) {
+        if (perm) {                                                    // randperm(num_data)  src/train.jl:93
+            PPO_TRY(h2d(permd.p, perm + (size_t)ep * len, (size_t)len));
+            hipLaunchKernelGGL(k_perm_index, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, g_stream, ro->index.p,
+                               permd.p, len, order.p, pol->err.p);
+            HIP_TRY(hipGetLastError());
+        } else {
+            PPO_TRY(launch_feistel_index(ro->index.p, len, seed, epoch_counter, order.p));
+        }
+        epoch_counter++;
+        int64_t b = 0;
+        for (int64_t start = 0; start < len; start += batch_size, ++b) {           // :95-96 (last batch may be short)
+            const int64_t B = (start + batch_size <= len) ? batch_size : (len - start);
+            PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, B * world, epsilon, entropy_weight));
+            if (world > 1) {
+                const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
+                if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }
+            }
+            hipLaunchKernelGGL(k_copy_tail, dim3(1), dim3(64), 0, g_stream, pol->grad.p + pol->np, hist.p + 2 * b);
+            PPO_TRY(launch_adam(opt));                                              // Flux.update!  :81
+        }
+        PPO_TRY(d2h(hh.data(), hist.p, (size_t)nb * 2));
+        double sp = 0.0, se = 0.0;
+        for (int64_t i = 0; i < nb; ++i) { sp += hh[2 * i]; se += hh[2 * i + 1]; }
+        if (ppo_hist) ppo_hist[ep] = sp / (double)nb;                               // unweighted mean over batches :127
+        if (entropy_hist) entropy_hist[ep] = se / (double)nb;
+        if (lr_hist) lr_hist[ep] = opt->eta;                                        // :144,155-158
+    }
+    int32_t f = 0;
+    PPO_TRY(d2h(&f, pol->err.p, 1));
+    if (f) { ppo_set_error("AssertionError (device flag): permutation / dataset index out of range"); return PPO_ERR_DEVICE_FLAG; }
+    return PPO_OK;
+}
+
+}  // extern "C"

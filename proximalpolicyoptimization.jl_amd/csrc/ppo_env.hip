@@ -1,0 +1,204 @@
+// ppo_env.hip -- K1: batched synthetic rand-poly-shaped env (plugin contract
+// src/ProximalPolicyOptimization.jl:16-20; tensor shapes test/quad_game_utilities.jl:39-59,95-110).
+// QuadMeshGame's dynamics are not in the reference tree, so this is an honest synthetic stand-in
+// with exactly specified integer dynamics (DESIGN.md "Synthetic env"): SoA state in HBM, one
+// thread per env for the integer update, one thread per output dword for the observation.
+#include "ppo_internal.h"
+#include "ppo_device.h"
+
+struct EnvView {
+    int8_t* score; int8_t* degree; uint32_t* active; int32_t* steps; float* reward; uint8_t* done;
+    uint32_t* episode; uint32_t* tick; int32_t* err; int32_t* episodes_left;
+    int32_t Q, V, max_actions; float no_action_reward; int64_t N, global_offset; uint32_t k0, k1;
+};
+
+static EnvView view_of(ppo_env_s* e) {
+    EnvView v;
+    v.score = e->score.p; v.degree = e->degree.p; v.active = e->active.p; v.steps = e->steps.p;
+    v.reward = e->reward.p; v.done = e->done.p; v.episode = e->episode.p; v.tick = e->tick.p; v.err = e->err.p;
+    v.episodes_left = e->episodes_left.p;
+    v.Q = e->Q; v.V = e->V; v.max_actions = e->max_actions; v.no_action_reward = e->no_action_reward;
+    v.N = e->N; v.global_offset = e->global_offset; v.k0 = (uint32_t)e->seed; v.k1 = (uint32_t)(e->seed >> 32);
+    return v;
+}
+
+__device__ __forceinline__ void env_reset_one(const EnvView& e, int64_t n) {
+    const int V = e.V, Q = e.Q, nact = (3 * Q) / 4;
+    int8_t* sc = e.score + n * V;
+    int8_t* dg = e.degree + n * V;
+    const uint32_t g = (uint32_t)(e.global_offset + n);
+    const uint32_t ep = e.episode[n];
+    for (int q = 0; q < Q; ++q) {
+        uint32_t w[4];
+        philox4x32_10(g, ep, 1u, (uint32_t)q, e.k0, e.k1, w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = 4 * q + i;
+            if (q < nact) {
+                const int s = (int)(w[i] % 5u) - 2;
+                const int desired = 3 + (int)((w[i] >> 8) & 1u);
+                sc[v] = (int8_t)s; dg[v] = (int8_t)(desired - s);
+            } else { sc[v] = 0; dg[v] = 0; }
+        }
+    }
+    e.active[n] = (nact >= 32) ? 0xFFFFFFFFu : ((1u << nact) - 1u);
+    e.steps[n] = 0; e.reward[n] = 0.0f; e.done[n] = 0;
+    e.episode[n] = ep + 1u;
+}
+
+__global__ void k_env_reset(EnvView e, int only_done) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    if (only_done && !e.done[n]) return;
+    env_reset_one(e, n);
+}
+
+__device__ __forceinline__ bool deg_ok(int d) { return d >= 2 && d <= 7; }
+
+__device__ __forceinline__ int total_abs(const int8_t* sc, uint32_t act, int Q) {
+    int s = 0;
+    for (int q = 0; q < Q; ++q) if ((act >> q) & 1u)
+        for (int i = 0; i < 4; ++i) { int x = sc[4 * q + i]; s += x < 0 ? -x : x; }
+    return s;
+}
+__device__ __forceinline__ int total_sum(const int8_t* sc, uint32_t act, int Q) {
+    int s = 0;
+    for (int q = 0; q < Q; ++q) if ((act >> q) & 1u)
+        for (int i = 0; i < 4; ++i) s += sc[4 * q + i];
+    return s;
+}
+
+// step!(env, a) for every env + record reward/is_terminal + optional auto-reset
+// (call order src/collect_rollouts.jl:9-12; reset before the next episode src/rollout_buffer.jl:75).
+__global__ void k_env_step(EnvView e, const int32_t* __restrict__ actions, float* __restrict__ reward_out,
+                           uint8_t* __restrict__ done_out, uint8_t* __restrict__ valid_out, int auto_reset,
+                           int episodes_mode) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= e.N) return;
+    if (episodes_mode && e.episodes_left[n] <= 0) {          // this env already played its episodes
+        if (valid_out) valid_out[n] = 0;
+        if (reward_out) reward_out[n] = 0.0f;
+        if (done_out) done_out[n] = 1;
+        return;
+    }
+    const int V = e.V, Q = e.Q, A = 16 * Q;
+    int8_t* sc = e.score + n * V;
+    int8_t* dg = e.degree + n * V;
+    uint32_t act = e.active[n];
+    int errf = 0;
+    e.tick[n] += 1u;
+    int a = actions[n];
+    if (e.done[n]) { atomicOr(e.err, 4); return; }
+    if (a < 0 || a >= A) { errf |= 2; a = 0; }
+    const int q = a / 16, ed = (a % 16) / 4, type = a % 4;
+    const int old_total = total_abs(sc, act, Q);
+    bool valid = false;
+    if (!((act >> q) & 1u)) {
+        errf |= 1;
+    } else {
+        const int v0 = 4 * q + ed, v1 = 4 * q + ((ed + 1) & 3), v2 = 4 * q + ((ed + 2) & 3), v3 = 4 * q + ((ed + 3) & 3);
+        const int nq = (q + 1 + ed) % Q;
+        const int w0 = 4 * nq + ed, w1 = 4 * nq + ((ed + 1) & 3);
+        const bool nq_ok = (nq != q) && ((act >> nq) & 1u);
+        if (type == 0 || type == 1) {
+            const int p = (type == 0) ? v3 : v2, r = (type == 0) ? w0 : w1;
+            if (nq_ok && deg_ok(dg[v0] - 1) && deg_ok(dg[v1] - 1) && deg_ok(dg[p] + 1) && deg_ok(dg[r] + 1)) {
+                dg[v0]--; sc[v0]++; dg[v1]--; sc[v1]++;
+                dg[p]++; sc[p]--; dg[r]++; sc[r]--;
+                valid = true;
+            }
+        } else if (type == 2) {
+            int f = -1;
+            for (int s = 0; s < Q; ++s) if (!((act >> s) & 1u)) { f = s; break; }
+            if (f >= 0 && deg_ok(dg[v0] + 1) && deg_ok(dg[v2] + 1)) {
+                dg[v0]++; sc[v0]--; dg[v2]++; sc[v2]--;
+                for (int i = 0; i < 4; ++i) { sc[4 * f + i] = 0; dg[4 * f + i] = 4; }
+                act |= (1u << f);
+                valid = true;
+            }
+        } else {
+            const int cnt = __popc(act);
+            if (nq_ok && cnt > Q / 2 && deg_ok(dg[w0] - 1) && deg_ok(dg[w1] - 1)) {
+                dg[w0]--; sc[w0]++; dg[w1]--; sc[w1]++;
+                for (int i = 0; i < 4; ++i) { sc[4 * q + i] = 0; dg[4 * q + i] = 0; }
+                act &= ~(1u << q);
+                valid = true;
+            }
+        }
+    }
+    if (errf) atomicOr(e.err, errf);
+    e.active[n] = act;
+    const int new_total = total_abs(sc, act, Q);
+    const float rew = valid ? (float)(old_total - new_total) : e.no_action_reward;
+    const int st = e.steps[n] + 1;
+    e.steps[n] = st;
+    const int sum = total_sum(sc, act, Q);
+    const int opt = sum < 0 ? -sum : sum;
+    const uint8_t dn = (uint8_t)((new_total == opt) || (st >= e.max_actions));
+    e.reward[n] = rew; e.done[n] = dn;
+    if (reward_out) reward_out[n] = rew;
+    if (done_out) done_out[n] = dn;
+    if (valid_out) valid_out[n] = 1;
+    if (dn) {
+        if (episodes_mode) {
+            const int left = e.episodes_left[n] - 1;
+            e.episodes_left[n] = left;
+            if (left > 0) env_reset_one(e, n);
+        } else if (auto_reset) {
+            env_reset_one(e, n);
+        }
+    }
+}
+
+// state(env): obs[n][h][f] int8, f<36 template scores, f>=36 template degrees, 0 where the
+// template entry is missing or its quad is inactive (test/quad_game_utilities.jl:35-37,46-59).
+// One thread per output dword (4 features): coalesced 4-byte stores.
+__global__ void k_env_observe(EnvView e, int8_t* __restrict__ obs, uint32_t* __restrict__ active_out) {
+    const int H = 4 * e.Q, F = 2 * PPO_TPL, V = e.V;
+    const int dw_per_env = H * F / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = gid / dw_per_env;
+    if (n >= e.N) return;
+    const int rem = (int)(gid - n * dw_per_env);
+    const int h = rem / (F / 4), f0 = (rem % (F / 4)) * 4;
+    const uint32_t act = e.active[n];
+    if (rem == 0 && active_out) active_out[n] = act;
+    const int8_t* src = (f0 < PPO_TPL) ? (e.score + n * V) : (e.degree + n * V);
+    const int t0 = (f0 < PPO_TPL) ? f0 : f0 - PPO_TPL;
+    const bool own = (act >> (h >> 2)) & 1u;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = env_template(e.Q, h, t0 + i);
+        const bool ok = own && v >= 0 && ((act >> (v >> 2)) & 1u);
+        const int8_t val = ok ? src[v] : (int8_t)0;
+        packed |= ((uint32_t)(uint8_t)val) << (8 * i);
+    }
+    reinterpret_cast<uint32_t*>(obs)[gid] = packed;
+}
+
+int32_t launch_env_reset(ppo_env_s* e, int only_done) {
+    dim3 grid((unsigned)((e->N + 255) / 256));
+    hipLaunchKernelGGL(k_env_reset, grid, dim3(256), 0, ppo_stream(), view_of(e), only_done);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_env_step(ppo_env_s* e, const int32_t* actions_dev, float* reward_out, uint8_t* done_out,
+                        uint8_t* valid_out, int auto_reset, int episodes_mode) {
+    ProfScope ps("k_env_step");
+    dim3 grid((unsigned)((e->N + 63) / 64));
+    hipLaunchKernelGGL(k_env_step, grid, dim3(64), 0, ppo_stream(), view_of(e), actions_dev, reward_out, done_out,
+                       valid_out, auto_reset, episodes_mode);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out) {
+    ProfScope ps("k_env_observe");
+    const int64_t total = e->N * (int64_t)(e->H * e->F / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipLaunchKernelGGL(k_env_observe, grid, dim3(256), 0, ppo_stream(), view_of(e), obs_out, active_out);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}

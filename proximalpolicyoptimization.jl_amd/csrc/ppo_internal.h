@@ -1,0 +1,149 @@
+// ppo_internal.h -- shared internals of libppo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/ppo_hip.h"
+
+#define PPO_OUT 4   // actions per half-edge (test/quad_game_utilities.jl:39,95)
+#define PPO_TPL 36  // template rows; F = 72
+
+// ---------------------------------------------------------------- host-side error plumbing
+void ppo_set_error(const std::string& msg);
+hipStream_t ppo_stream();
+int ppo_hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) return ppo_hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+#define ARG_CHECK(cond, msg)                                                 \
+    do {                                                                     \
+        if (!(cond)) { ppo_set_error(std::string("AssertionError: ") + msg + " [" #cond "]"); return PPO_ERR_ARG; } \
+    } while (0)
+#define PPO_TRY(expr)                                                        \
+    do { int32_t _s = (expr); if (_s != PPO_OK) return _s; } while (0)
+
+// kernel timing registry (bench roofline leg)
+struct ProfScope {
+    const char* name; hipEvent_t e0, e1; bool on;
+    ProfScope(const char* n);
+    ~ProfScope();
+};
+
+// ---------------------------------------------------------------- device buffers
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t n = 0;
+    int32_t alloc(size_t count) {
+        if (count <= n && p) return PPO_OK;
+        release();
+        if (count == 0) return PPO_OK;
+        HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+        return PPO_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// ---------------------------------------------------------------- handles
+struct ppo_env_s {
+    int32_t kind, Q, H, A, V, F, max_actions;
+    float no_action_reward;
+    int64_t N, global_offset;
+    uint64_t seed;
+    DevBuf<int8_t> score, degree;      // [N][V]
+    DevBuf<uint32_t> active;           // [N]
+    DevBuf<int32_t> steps;             // [N]
+    DevBuf<float> reward;              // [N]
+    DevBuf<uint8_t> done;              // [N]
+    DevBuf<uint32_t> episode, tick;    // [N]
+    DevBuf<int32_t> err;               // [1] OR of error flags
+    DevBuf<int32_t> actions_tmp;       // [N]
+    DevBuf<int8_t> obs_tmp;            // [N][H][F]
+    DevBuf<int32_t> episodes_left;     // [N] (episodes mode)
+};
+
+struct ppo_policy_s {
+    int32_t F, HID, L, OUT;
+    int64_t np;
+    // canonical flat parameters (Flux order) + packed MFMA-fragment copies
+    DevBuf<float> params;              // [np]
+    DevBuf<float> w1p, w2p, w2tp;      // A-operand fragment order
+    DevBuf<float> b1p, b2p, w3p, b3;   // accumulator-init / VALU packs
+    DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
+    // training workspace
+    DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4
+    DevBuf<float> dY;                  // [tiles][32][4]
+    DevBuf<double> loss_terms;         // [tiles][2]
+    DevBuf<float> slabs;               // [nwg][slab]
+    DevBuf<int32_t> idx;               // gathered transition ids of the minibatch
+    DevBuf<int32_t> err;               // device error flag
+    int64_t cap_tiles = 0;
+    int32_t nwg_bwd = 0;
+    int64_t last_B = 0;
+    double last_entropy_weight = 0.0;
+};
+
+struct ppo_adam_s {
+    ppo_policy_s* pol;
+    double eta, beta1, beta2, eps;
+    double beta_pow[2];
+    DevBuf<float> m, v;
+};
+
+struct ppo_rollouts_s {
+    int64_t N, capT, T;    // T = steps currently held
+    int32_t H, F, A;
+    int64_t len;           // valid transitions
+    DevBuf<int8_t> states;     // [T][N][H][F]
+    DevBuf<uint32_t> active;   // [T][N]
+    DevBuf<int32_t> actions;   // [T][N]
+    DevBuf<float> p_sel;       // [T][N]
+    DevBuf<float> rewards;     // [T][N] raw
+    DevBuf<float> returns;     // [T][N]
+    DevBuf<uint8_t> done;      // [T][N]
+    DevBuf<uint8_t> valid;     // [T][N]
+    DevBuf<int32_t> index;     // [len] transition ids in dataset order
+    DevBuf<float> full_probs;  // [T][N][A] optional
+    bool all_valid = true;
+};
+
+// ---------------------------------------------------------------- packed layout sizes
+static inline size_t slab_floats(int F, int HID) {
+    const int FP = ((F + 31) / 32) * 32;
+    return (size_t)HID * HID + (size_t)HID * FP + (size_t)HID * 2 + (size_t)HID * PPO_OUT + 64;
+}
+
+// ---------------------------------------------------------------- kernel launchers (defined in the .hip files)
+int32_t launch_returns_tn(const float* r, const uint8_t* done, float* out, int64_t T, int64_t N,
+                          double discount, int f32mode);
+int32_t launch_returns_flat(const float* r, const uint8_t* term, float* out, int64_t n, double discount, int f32mode);
+int32_t launch_gae_tn(const float* r, const uint8_t* done, const float* values, float* adv, float* ret,
+                      int64_t T, int64_t N, double gamma, double lambda);
+
+int32_t launch_env_reset(ppo_env_s* e, int only_done);
+int32_t launch_env_step(ppo_env_s* e, const int32_t* actions_dev, float* reward_out, uint8_t* done_out,
+                        uint8_t* valid_out, int auto_reset, int episodes_mode);
+int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out);
+
+int32_t launch_pack_params(ppo_policy_s* p);
+int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uint32_t* active_dev, int64_t B,
+                            float* probs_dev);
+int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
+                              int32_t* actions_out, float* psel_out, float* full_probs_or_null);
+int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
+                                int64_t B_global, double eps, double entropy_weight);
+int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B);
+int32_t launch_adam(ppo_adam_s* o);
+int32_t launch_categorical(const float* probs, const float* u, int64_t B, int64_t A, int32_t* actions, float* psel,
+                           int32_t* err);
+int32_t launch_feistel_index(const int32_t* index_dev, int64_t len, uint64_t seed, uint32_t epoch, int32_t* out_dev);

@@ -1,0 +1,194 @@
+// ppo_optim.hip -- gradient slab reduction, K12 Adam (Flux legacy Adam + Flux.update!,
+// src/train.jl:81; semantics SURVEY.md Appendix A) and the re-packing of the updated parameters
+// into the MFMA A-operand fragment orders used by the forward/backward kernels.
+#include "ppo_internal.h"
+#include "ppo_device.h"
+
+struct ParamLayout {
+    int F, HID, NT, FP, NI;
+    int64_t offW1, offb1, offW2, offb2, offW3, offb3, np;
+};
+
+static ParamLayout layout_of(const ppo_policy_s* p) {
+    ParamLayout L;
+    L.F = p->F; L.HID = p->HID; L.NT = p->HID / 32; L.FP = ((p->F + 31) / 32) * 32; L.NI = L.FP / 32;
+    L.offW1 = 0; L.offb1 = (int64_t)p->HID * p->F; L.offW2 = L.offb1 + p->HID;
+    L.offb2 = L.offW2 + (int64_t)p->HID * p->HID; L.offW3 = L.offb2 + p->HID;
+    L.offb3 = L.offW3 + (int64_t)PPO_OUT * p->HID; L.np = L.offb3 + PPO_OUT;
+    return L;
+}
+
+// ---------------------------------------------------------------- slab reduce
+// One thread per slab element (coalesced reads across slabs); fixed summation order.
+__global__ void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg, ParamLayout L,
+                              float* __restrict__ grad) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
+    const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
+    if (e >= total) return;
+    float s = 0.0f;
+    for (int g = 0; g < nwg; ++g) s += slabs[(size_t)g * slab_stride + e];
+    int64_t canon = -1;
+    if (e < nW2) {
+        const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
+        const int tile = (int)(e >> 10), kt = tile % L.NT, ft = tile / L.NT;
+        const int f = dfeat(ft, r, lane >> 5), k = 32 * kt + (lane & 31);
+        canon = L.offW2 + f + (int64_t)L.HID * k;
+    } else if (e < nW2 + nW1) {
+        const size_t e1 = e - nW2;
+        const int lane = (int)(e1 & 63), r = (int)((e1 >> 6) & 15);
+        const int tile = (int)(e1 >> 10), it = tile % L.NI, ft = tile / L.NI;
+        const int ko = dfeat(ft, r, lane >> 5), i = 32 * it + (lane & 31);
+        if (i < L.F) canon = L.offW1 + ko + (int64_t)L.HID * i;
+    } else {
+        size_t e2 = e - nW2 - nW1;
+        if (e2 < (size_t)L.HID) canon = L.offb1 + (int64_t)e2;
+        else if ((e2 -= L.HID) < (size_t)L.HID) canon = L.offb2 + (int64_t)e2;
+        else if ((e2 -= L.HID) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
+        else canon = L.offb3 + (int64_t)(e2 - (size_t)L.HID * 4);
+    }
+    if (canon >= 0) grad[canon] = s;
+}
+
+// loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global
+__global__ void k_loss_reduce(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
+                              float* __restrict__ grad_tail) {
+    __shared__ double s0[256], s1[256];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < B; i += 256) { a += terms[2 * i]; b += terms[2 * i + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        grad_tail[0] = (float)(-(s0[0] * inv_Bg));
+        grad_tail[1] = (float)(entropy_weight * (-(s1[0] * inv_Bg)));
+    }
+}
+
+// ---------------------------------------------------------------- Adam + pack
+struct PackPtrs { float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3; };
+
+__device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P, int64_t i, float x) {
+    const int HID = L.HID, F = L.F, NT = L.NT;
+    if (i < L.offb1) {                                   // W1[io][k]  (layer-1 A operand)
+        const int io = (int)(i % HID), k = (int)(i / HID);
+        const int hh = k / (F / 2), s = k % (F / 2);
+        P.w1p[((size_t)((io >> 5) * (F / 8) + (s >> 2)) * 64 + (io & 31) + 32 * hh) * 4 + (s & 3)] = x;
+    } else if (i < L.offW2) {
+        const int f = (int)(i - L.offb1), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        P.b1p[((f >> 5) * 2 + hh) * 16 + r] = x;
+    } else if (i < L.offb2) {                            // W2[f][k]
+        const int64_t e = i - L.offW2;
+        const int f = (int)(e % HID), k = (int)(e / HID);
+        {   // forward A operand: out f, contraction in layer-1 accumulator-register order
+            const int kk = k & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+            const int s = 16 * (k >> 5) + r;
+            P.w2p[((size_t)((f >> 5) * (HID / 8) + (s >> 2)) * 64 + (f & 31) + 32 * hh) * 4 + (s & 3)] = x;
+        }
+        {   // backward A operand (W2^T): out k, contraction f = 2s + hh
+            const int s = f >> 1, hh = f & 1;
+            P.w2tp[((size_t)((k >> 5) * (HID / 8) + (s >> 2)) * 64 + (k & 31) + 32 * hh) * 4 + (s & 3)] = x;
+        }
+    } else if (i < L.offW3) {
+        const int f = (int)(i - L.offb2), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        P.b2p[((f >> 5) * 2 + hh) * 16 + r] = x;
+    } else if (i < L.offb3) {                            // W3[oo][k]
+        const int64_t e = i - L.offW3;
+        const int oo = (int)(e & 3), k = (int)(e >> 2);
+        const int kk = k & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        P.w3p[((size_t)(hh * NT + (k >> 5)) * 16 + r) * 4 + oo] = x;
+    } else {
+        P.b3[i - L.offb3] = x;
+    }
+}
+
+__global__ void k_pack_params(const float* __restrict__ params, ParamLayout L, PackPtrs P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.np) return;
+    pack_one(L, P, i, params[i]);
+}
+
+// Flux legacy Adam: element arithmetic in Float64 (Float64 hyper-parameters against Float32
+// arrays), Float32 stores; bias-correction powers tracked in Float64 on the host.
+__global__ void k_adam(float* __restrict__ params, const float* __restrict__ grad, float* __restrict__ m,
+                       float* __restrict__ v, ParamLayout L, PackPtrs P, double eta, double beta1, double beta2,
+                       double eps, double bp1, double bp2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.np) return;
+    const double gd = (double)grad[i];
+    const float mn = (float)(beta1 * (double)m[i] + (1.0 - beta1) * gd);
+    const float vn = (float)(beta2 * (double)v[i] + ((1.0 - beta2) * gd) * gd);
+    m[i] = mn; v[i] = vn;
+    const double delta = (double)mn / (1.0 - bp1) / (sqrt((double)vn / (1.0 - bp2)) + eps) * eta;
+    const float x = params[i] - (float)delta;
+    params[i] = x;
+    pack_one(L, P, i, x);
+}
+
+// dataset order -> minibatch order: out[i] = index[perm_epoch(i)]
+__global__ void k_feistel_index(const int32_t* __restrict__ index, int64_t len, uint64_t seed, uint32_t epoch,
+                                int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    out[i] = index[feistel_perm(i, len, seed, epoch)];
+}
+
+static PackPtrs packs_of(ppo_policy_s* p) {
+    PackPtrs P;
+    P.w1p = p->w1p.p; P.w2p = p->w2p.p; P.w2tp = p->w2tp.p; P.b1p = p->b1p.p; P.b2p = p->b2p.p; P.w3p = p->w3p.p;
+    P.b3 = p->b3.p;
+    return P;
+}
+
+int32_t launch_pack_params(ppo_policy_s* p) {
+    ParamLayout L = layout_of(p);
+    hipLaunchKernelGGL(k_pack_params, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, ppo_stream(), p->params.p, L,
+                       packs_of(p));
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B) {
+    ParamLayout L = layout_of(p);
+    const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
+    {
+        ProfScope ps("k_grad_reduce");
+        hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppo_stream(),
+                           p->slabs.p, slab_floats(p->F, p->HID), p->nwg_bwd, L, p->grad.p);
+    }
+    (void)B;
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_loss_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight) {
+    ParamLayout L = layout_of(p);
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, ppo_stream(), p->loss_terms.p, B, 1.0 / (double)B_global,
+                       entropy_weight, p->grad.p + L.np);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_adam(ppo_adam_s* o) {
+    ppo_policy_s* p = o->pol;
+    ParamLayout L = layout_of(p);
+    ProfScope ps("k_adam");
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, ppo_stream(), p->params.p, p->grad.p,
+                       o->m.p, o->v.p, L, packs_of(p), o->eta, o->beta1, o->beta2, o->eps, o->beta_pow[0],
+                       o->beta_pow[1]);
+    HIP_TRY(hipGetLastError());
+    o->beta_pow[0] *= o->beta1;
+    o->beta_pow[1] *= o->beta2;
+    return PPO_OK;
+}
+
+int32_t launch_feistel_index(const int32_t* index_dev, int64_t len, uint64_t seed, uint32_t epoch, int32_t* out_dev) {
+    if (len <= 0) return PPO_OK;
+    hipLaunchKernelGGL(k_feistel_index, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ppo_stream(), index_dev, len,
+                       seed, epoch, out_dev);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}

@@ -1,0 +1,143 @@
+// ppo_returns.hip -- K6: discounted-return / GAE reverse scans (src/collect_rollouts.jl:26-42).
+//
+// Hot layout is time-major [T,N]: lanes = envs (coalesced rows), the scan runs along T.
+// The recurrence is strictly sequential per column and the reference's running value is a
+// Float64 (SURVEY.md hard part 3), so the arithmetic is NOT re-associated: a workgroup owns 64
+// columns, its 4 waves each load a 32-row time chunk into registers in parallel (the HBM-bound
+// part), then the chunks are chained latest-first through a 64-entry fp64 carry staged in LDS.
+// Results are bit-identical to the sequential reference loop.
+//
+// Roofline: HBM-bound, 9 B per transition (r f32 + done u8 in, return f32 out).
+#include "ppo_internal.h"
+#include "ppo_device.h"
+
+#define RT_CH 32          // rows per wave per pass
+#define RT_WAVES 4
+#define RT_COLS 64
+
+template <int F32MODE>
+__global__ __launch_bounds__(256) void k_returns_tn(const float* __restrict__ r, const uint8_t* __restrict__ done,
+                                                    float* __restrict__ out, int64_t T, int64_t N, double discount) {
+    __shared__ double sCarry[RT_COLS];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * RT_COLS + lane;
+    const bool col_ok = n < N;
+    const float gf = (float)discount;
+    const int64_t npass = (T + RT_CH * RT_WAVES - 1) / (RT_CH * RT_WAVES);
+    if (w == RT_WAVES - 1) sCarry[lane] = 0.0;
+    __syncthreads();
+    for (int64_t p = 0; p < npass; ++p) {
+        const int64_t base = T - (int64_t)RT_CH * RT_WAVES * (p + 1) + (int64_t)RT_CH * w;   // may be < 0
+        float rr[RT_CH];
+        uint8_t dd[RT_CH];
+#pragma unroll
+        for (int i = 0; i < RT_CH; ++i) {
+            const int64_t t = base + i;
+            const bool ok = col_ok && t >= 0;
+            rr[i] = ok ? r[t * N + n] : 0.0f;
+            dd[i] = ok ? done[t * N + n] : (uint8_t)0;
+        }
+        // chain the four chunks latest-first; each wave runs the exact sequential recurrence
+        for (int ww = RT_WAVES - 1; ww >= 0; --ww) {
+            if (w == ww) {
+                if (F32MODE) {
+                    float v = (float)sCarry[lane];
+#pragma unroll
+                    for (int i = RT_CH - 1; i >= 0; --i) {
+                        const int64_t t = base + i;
+                        if (t >= 0) {
+                            if (dd[i]) v = 0.0f;
+                            float gv = gf * v;
+                            v = rr[i] + gv;
+                            if (col_ok) out[t * N + n] = v;
+                        }
+                    }
+                    sCarry[lane] = (double)v;
+                } else {
+                    double v = sCarry[lane];
+#pragma unroll
+                    for (int i = RT_CH - 1; i >= 0; --i) {
+                        const int64_t t = base + i;
+                        if (t >= 0) {
+                            if (dd[i]) v = 0.0;
+                            double gv = discount * v;
+                            v = (double)rr[i] + gv;
+                            if (col_ok) out[t * N + n] = (float)v;
+                        }
+                    }
+                    sCarry[lane] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Flat concatenated-episodes layout (the reference's own): each episode segment is scanned by
+// the thread that owns its last element, so the arithmetic is again the sequential recurrence.
+template <int F32MODE>
+__global__ void k_returns_flat(const float* __restrict__ r, const uint8_t* __restrict__ term, float* __restrict__ out,
+                               int64_t n, double discount) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!(term[i] || i == n - 1)) return;
+    const float gf = (float)discount;
+    int64_t j = i;
+    if (F32MODE) {
+        float v = 0.0f;
+        do { float gv = gf * v; v = r[j] + gv; out[j] = v; --j; } while (j >= 0 && !term[j]);
+    } else {
+        double v = 0.0;
+        do { double gv = discount * v; v = (double)r[j] + gv; out[j] = (float)v; --j; } while (j >= 0 && !term[j]);
+    }
+}
+
+// GAE(gamma, lambda) extension (no reference counterpart); one lane per column, fp64 running value.
+__global__ void k_gae_tn(const float* __restrict__ r, const uint8_t* __restrict__ done, const float* __restrict__ val,
+                         float* __restrict__ adv, float* __restrict__ ret, int64_t T, int64_t N, double gamma,
+                         double lambda) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double a = 0.0;
+    const double gl = gamma * lambda;
+    for (int64_t t = T - 1; t >= 0; --t) {
+        const double nd = done[t * N + n] ? 0.0 : 1.0;
+        const double vnext = (double)val[(t + 1) * N + n] * nd;
+        const double gvn = gamma * vnext;
+        const double delta = ((double)r[t * N + n] + gvn) - (double)val[t * N + n];
+        const double carry = (gl * nd) * a;
+        a = delta + carry;
+        adv[t * N + n] = (float)a;
+        ret[t * N + n] = (float)(a + (double)val[t * N + n]);
+    }
+}
+
+int32_t launch_returns_tn(const float* r, const uint8_t* done, float* out, int64_t T, int64_t N, double discount,
+                          int f32mode) {
+    if (T <= 0 || N <= 0) return PPO_OK;
+    ProfScope ps("k_returns_tn");
+    dim3 grid((unsigned)((N + RT_COLS - 1) / RT_COLS));
+    if (f32mode) hipLaunchKernelGGL(k_returns_tn<1>, grid, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
+    else hipLaunchKernelGGL(k_returns_tn<0>, grid, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_returns_flat(const float* r, const uint8_t* term, float* out, int64_t n, double discount, int f32mode) {
+    if (n <= 0) return PPO_OK;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (f32mode) hipLaunchKernelGGL(k_returns_flat<1>, grid, dim3(256), 0, ppo_stream(), r, term, out, n, discount);
+    else hipLaunchKernelGGL(k_returns_flat<0>, grid, dim3(256), 0, ppo_stream(), r, term, out, n, discount);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_gae_tn(const float* r, const uint8_t* done, const float* values, float* adv, float* ret, int64_t T,
+                      int64_t N, double gamma, double lambda) {
+    if (T <= 0 || N <= 0) return PPO_OK;
+    dim3 grid((unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(k_gae_tn, grid, dim3(64), 0, ppo_stream(), r, done, values, adv, ret, T, N, gamma, lambda);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
