@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end PPO throughput of the MI355X engine (BASELINE.json metric).
+
+One "step" = one PPO iteration over synthetic input: rollout of N parallel envs for T steps (batched env
+step + policy forward + masked softmax + categorical sample + record), the discounted-return scan, and E
+epochs of minibatch updates (forward + loss + backward + Adam) over all N*T transitions.
+Workload (BASELINE configs[1], survey-chosen sizes SURVEY.md 8(d)): 4096 synthetic rand-poly-shaped envs
+(Q=8 -> H=32 half-edges, A=128 actions, F=72 int8 features), policy Dense(72,256)->Dense(256,256)->Dense(256,4)
+fp32, T=128, E=4 epochs, minibatch 4096 per GPU, gamma=1.0, eps=0.05, entropy weight 0.01, Adam 1e-4.
+Multi-GPU (one process per GPU, torchrun): 4096 envs PER GPU (weak scaling), one RCCL all-reduce of the flat
+gradient per optimiser step; no other exchange.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+N_ENVS, T_STEPS, HID, F, EPOCHS, MINIBATCH = 4096, 128, 256, 72, 4, 4096
+GAMMA, EPS, ENT_W, LR = 1.0, 0.05, 0.01, 1e-4
+PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def flops_per_state(kind):
+    """Algorithmic flops of one 32-row state tile on the matrix pipe (DESIGN.md 'Kernels')."""
+    fwd = 2 * 32 * (F * HID + HID * HID + HID * 4)
+    if kind == "fwd":
+        return fwd
+    # backward: dH1 = W2^T dZ2 (HID*HID), dW2 (HID*HID), dW1 (HID*F), dW3/dH2 (2*HID*4)
+    return 2 * 32 * (2 * HID * HID + HID * F + 2 * HID * 4)
+
+
+def cpu_baseline():
+    """The CPU restatement of the Julia path (oracle/, 1 core) timed on a bounded sample of the same workload:
+    serial per-step forward/sample/step, serial scan, per-minibatch forward+backward+Adam."""
+    from oracle import oracle as orc
+    n_env, T, B = 4, 48, 64
+    params = orc.glorot_params(F, HID, 2, seed=0)
+    env = orc.Env(Q=8, max_actions=T_STEPS, N=n_env, seed=1234)
+    env.reset()
+    t0 = time.perf_counter()
+    ro = orc.collect_rollouts_tn(env, params, HID, T, mode_dev=False)
+    ret = orc.compute_returns_tn(ro["rewards"], ro["done"], GAMMA)
+    M = n_env * T
+    st = ro["states"].reshape(M, 32, F)
+    act = ro["active"].reshape(M)
+    a0 = ro["actions"].reshape(M)
+    po = ro["p_sel"].reshape(M)
+    adv = ret.reshape(M)
+    m, v, bp = np.zeros_like(params), np.zeros_like(params), np.array([0.9, 0.999])
+    rng = np.random.default_rng(0)
+    for _ in range(EPOCHS):
+        perm = rng.permutation(M)
+        for s in range(0, M, B):
+            sel = perm[s:s + B]
+            g, _, _ = orc.step_batch_grad_f64(params, F, HID, st[sel], act[sel], a0[sel], po[sel], adv[sel], EPS, ENT_W)
+            orc.adam_step(params, g.astype(np.float32), m, v, bp, LR)
+    dt = time.perf_counter() - t0
+    return {"value": M / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "CPU restatement of the Julia path (Julia unavailable): %d envs x %d steps, %d epochs, "
+                      "minibatch %d, 2x256 MLP, %.1f s on 1 core" % (n_env, T, EPOCHS, B, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import ctypes as C
+    import ppo_amd as PPO
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    PPO._lib.call("ppo_device_init", local_rank)
+    if world > 1:
+        PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    dp = PPO.DataParallel(rank, world)
+    env = PPO.HipVecEnv(num_envs=N_ENVS, Q=8, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
+    pol = PPO.HipPolicy(F, HID, 2, 4, seed=0)
+    opt = PPO.Optimiser(PPO.Adam(LR))
+    ro = PPO.BufferRollouts()
+
+    def iteration(i):
+        PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
+        ds = PPO.construct_dataset(ro)
+        PPO.ppo_train_(pol, opt, ds, EPS, MINIBATCH, EPOCHS, ENT_W, seed=1000 + i, parallel=dp, verbose=False)
+
+    def sync():
+        PPO.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        iteration(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        iteration(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline leg: per-kernel HIP-event durations of one more iteration (outside the timed region)
+    roof, kernels = None, {}
+    if rank == 0:
+        PPO.profile_enable(True)
+        iteration(args.warmup + args.steps)
+        PPO.synchronize()
+        for name, kind, per in [("k_policy_bwd", "bwd", MINIBATCH), ("k_policy_fwd_train", "fwd", MINIBATCH),
+                                ("k_policy_fwd_rollout", "fwd", N_ENVS)]:
+            ms, n = PPO.profile_get(name)
+            if n:
+                avg = ms / n
+                tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
+                kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
+                                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        for name in ("k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam"):
+            ms, n = PPO.profile_get(name)
+            if n:
+                kernels[name] = {"avg_ms": round(ms / n, 4), "launches": n}
+        PPO.profile_enable(False)
+        k = kernels.get("k_policy_bwd")
+        if k:
+            roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": k["frac"], "traffic": None}
+    elif world > 1:
+        iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
+        PPO.synchronize()
+
+    if rank == 0:
+        value = world * N_ENVS * T_STEPS * args.steps / dt
+        out = {
+            "metric": "env-steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "4096 parallel synthetic rand-poly-shaped envs per GPU (Q=8,H=32,A=128,F=72 int8), "
+                                   "2x256 MLP policy fp32, T=128 steps/iteration, 4 epochs, minibatch 4096/GPU, "
+                                   "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)",
+                       "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
+                       "parallelism": "dp%d" % world},
+            "roofline": roof, "kernels": kernels,
+            "target_frac_of_1e6": value / 1e6,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:      # the oracle is only a reported baseline
+                out["cpu_baseline"] = {"value": None, "error": str(e)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
