@@ -302,11 +302,14 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers, 
     p->F = F; p->HID = hidden; p->L = num_hidden_layers; p->OUT = out_per_edge;
     p->np = (int64_t)hidden * F + hidden + (int64_t)hidden * hidden + hidden + (int64_t)PPO_OUT * hidden + PPO_OUT;
     int32_t s = PPO_OK;
-    if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F)) || (s = p->w2p.alloc((size_t)hidden * hidden)) ||
-        (s = p->w2tp.alloc((size_t)hidden * hidden)) || (s = p->b1p.alloc(hidden)) || (s = p->b2p.alloc(hidden)) ||
+    if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F + PPO_PACK_PAD)) || (s = p->w2p.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) ||
+        (s = p->w2tp.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) || (s = p->b1p.alloc(hidden)) || (s = p->b2p.alloc(hidden)) ||
         (s = p->w3p.alloc((size_t)hidden * PPO_OUT)) || (s = p->b3.alloc(PPO_OUT)) || (s = p->grad.alloc(p->np + 2)) ||
         (s = p->err.alloc(1))) { delete p; return s; }
     (void)hipMemsetAsync(p->params.p, 0, p->np * 4, g_stream);
+    (void)hipMemsetAsync(p->w1p.p, 0, p->w1p.n * 4, g_stream);
+    (void)hipMemsetAsync(p->w2p.p, 0, p->w2p.n * 4, g_stream);
+    (void)hipMemsetAsync(p->w2tp.p, 0, p->w2tp.n * 4, g_stream);
     (void)hipMemsetAsync(p->grad.p, 0, (p->np + 2) * 4, g_stream);
     (void)hipMemsetAsync(p->err.p, 0, 4, g_stream);
     s = launch_pack_params(p);

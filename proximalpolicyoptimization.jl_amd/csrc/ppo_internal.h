@@ -9,6 +9,7 @@
 
 #define PPO_OUT 4   // actions per half-edge (test/quad_game_utilities.jl:39,95)
 #define PPO_TPL 36  // template rows; F = 72
+#define PPO_PACK_PAD (16 * 64 * 4)   // floats of zero tail padding behind each packed weight stream (prefetch over-read)
 
 // ---------------------------------------------------------------- host-side error plumbing
 void ppo_set_error(const std::string& msg);

@@ -26,8 +26,16 @@ __global__ void k_grad_reduce(const float* __restrict__ slabs, size_t slab_strid
     const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
     const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     if (e >= total) return;
-    float s = 0.0f;
-    for (int g = 0; g < nwg; ++g) s += slabs[(size_t)g * slab_stride + e];
+    // fixed summation order (8 interleaved partial sums, then a fixed tree): deterministic, and the 8
+    // independent loads in flight hide the HBM latency of the slab walk
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 8 <= nwg; g += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ps[u] += slabs[(size_t)(g + u) * slab_stride + e];
+    }
+    for (int u = 0; g < nwg; ++g, ++u) ps[u] += slabs[(size_t)g * slab_stride + e];
+    const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     int64_t canon = -1;
     if (e < nW2) {
         const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int S41 = F / 8;         // float4 groups of layer-1 k-steps
     constexpr int XB = F / 2;          // bytes of the state row held by one lane
     constexpr int XW = XB / 4;
+    constexpr int PF = 8;              // weight-fragment groups kept in flight per wave
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;           // half-edge row
@@ -87,69 +88,91 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
         }
 
         // ---- layer 1: H1^T[o-tile] = W1[o-tile,:] * X^T  (accumulator initialised with the bias)
+        // The weight stream of a layer is one linear run of 1 KiB fragment groups (4 MFMA k-steps each);
+        // a PF-deep register ring keeps PF groups in flight so the single wave of a SIMD never waits on L2.
         f32x16 h1[NT];
+        {
+            const float4* wp = a.w1p + lane;
+            float4 ring[PF];
 #pragma unroll
-        for (int o = 0; o < NT; ++o) {
-            f32x16 acc;
+            for (int g = 0; g < PF; ++g) ring[g] = wp[(size_t)g * 64];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = a.b1p[(o * 2 + h) * 4 + q];
-                acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
-            }
+            for (int o = 0; o < NT; ++o) {
+                f32x16 acc;
 #pragma unroll
-            for (int s4 = 0; s4 < S41; ++s4) {
-                const float4 w = a.w1p[(size_t)(o * S41 + s4) * 64 + lane];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xf[4 * s4 + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xf[4 * s4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xf[4 * s4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xf[4 * s4 + 3], acc, 0, 0, 0);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = a.b1p[(o * 2 + h) * 4 + q];
+                    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
-            h1[o] = acc;
-            if (MODE == 2) {
-                float4* dst = a.act1 + ((size_t)tile * NT + o) * 4 * 64;
+                for (int s4 = 0; s4 < S41; ++s4) {
+                    const int g = o * S41 + s4;
+                    const float4 w = ring[g % PF];
+                    ring[g % PF] = wp[(size_t)(g + PF) * 64];      // the packed buffers carry PF groups of tail padding
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, xf[4 * s4 + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, xf[4 * s4 + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xf[4 * s4 + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xf[4 * s4 + 3], acc, 0, 0, 0);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                h1[o] = acc;
+                if (MODE == 2) {
+                    float4* dst = a.act1 + ((size_t)tile * NT + o) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
             }
         }
 
         // ---- layer 2 (MFMA, B operands = layer-1 accumulators) + layer 3 (VALU dot epilogue)
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        {
+            constexpr int S42 = NT * 4;                  // groups per output tile
+            static_assert(S42 % PF == 0, "ring depth must divide the groups per tile");
+            const float4* wp = a.w2p + lane;
+            float4 ring[PF];
+#pragma unroll
+            for (int g = 0; g < PF; ++g) ring[g] = wp[(size_t)g * 64];
 #pragma unroll 1
-        for (int o = 0; o < NT; ++o) {
-            f32x16 acc;
+            for (int o = 0; o < NT; ++o) {
+                f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = a.b2p[(o * 2 + h) * 4 + q];
-                acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 w = a.w2p[(size_t)((o * NT + t) * 4 + r4) * 64 + lane];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h1[t][4 * r4 + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h1[t][4 * r4 + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h1[t][4 * r4 + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[t][4 * r4 + 3], acc, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = a.b2p[(o * 2 + h) * 4 + q];
+                    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                 }
-            }
+                const float4* wo = wp + (size_t)o * S42 * 64;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
-            if (MODE == 2) {
-                float4* dst = a.act2 + ((size_t)tile * NT + o) * 4 * 64;
+                for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            }
-            const float4* w3 = a.w3p + (size_t)(h * NT + o) * 16;
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int s4 = t * 4 + r4;
+                        const float4 w = ring[s4 % PF];
+                        // next group PF ahead in the linear stream (tail padding covers the last tile's over-read)
+                        ring[s4 % PF] = wo[(size_t)(s4 + PF) * 64];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h1[t][4 * r4 + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h1[t][4 * r4 + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h1[t][4 * r4 + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[t][4 * r4 + 3], acc, 0, 0, 0);
+                    }
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float4 w = w3[r];
-                p0 = fmaf(w.x, acc[r], p0); p1 = fmaf(w.y, acc[r], p1);
-                p2 = fmaf(w.z, acc[r], p2); p3 = fmaf(w.w, acc[r], p3);
+                for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                if (MODE == 2) {
+                    float4* dst = a.act2 + ((size_t)tile * NT + o) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+                const float4* w3 = a.w3p + (size_t)(h * NT + o) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 w = w3[r];
+                    p0 = fmaf(w.x, acc[r], p0); p1 = fmaf(w.y, acc[r], p1);
+                    p2 = fmaf(w.z, acc[r], p2); p3 = fmaf(w.w, acc[r], p3);
+                }
             }
         }
         float l[4];
