@@ -1,0 +1,146 @@
+# ProximalPolicyOptimizationHIP.jl -- reference-side binding of libppo_hip.so (include/ppo_hip.h).
+#
+# NOT EXECUTED in the build container (no `julia` binary; SURVEY.md 8(c)).  It is the binding a
+# maintainer of ProximalPolicyOptimization.jl would add: methods of the package's own generic
+# functions (src/ProximalPolicyOptimization.jl:16-30) for GPU-resident types, each a thin `ccall`.
+# Derived mechanically from include/ppo_hip.h; the Python mirror
+# (proximalpolicyoptimization.jl_amd/__init__.py) is the tested twin of this file.
+module ProximalPolicyOptimizationHIP
+
+using ProximalPolicyOptimization
+const PPO = ProximalPolicyOptimization
+const LIB = get(ENV, "PPO_HIP_LIB", "libppo_hip.so")
+
+function check(status::Int32)
+    status == 0 && return
+    buf = Vector{UInt8}(undef, 1024)
+    ccall((:ppo_last_error, LIB), Int32, (Ptr{UInt8}, Int64), buf, 1024)
+    msg = unsafe_string(pointer(buf))
+    startswith(msg, "AssertionError") ? throw(AssertionError(msg)) : error(msg)
+end
+
+# ---------------------------------------------------------------- handles
+mutable struct HipVecEnv
+    h::Ptr{Cvoid}; N::Int; Q::Int; H::Int; F::Int; A::Int
+    function HipVecEnv(num_envs; Q = 8, max_actions = 128, no_action_reward = -4f0, seed = 1234, global_offset = 0)
+        r = Ref{Ptr{Cvoid}}()
+        check(ccall((:ppo_env_create, LIB), Int32, (Int32, Int64, Int64, Int32, Int32, Float32, UInt64, Ref{Ptr{Cvoid}}),
+                    0, num_envs, global_offset, Q, max_actions, no_action_reward, seed, r))
+        e = new(r[], num_envs, Q, 4Q, 72, 16Q)
+        finalizer(x -> ccall((:ppo_env_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), e)
+    end
+end
+
+mutable struct HipPolicy
+    h::Ptr{Cvoid}; nparams::Int
+    function HipPolicy(in_channels, hidden_channels, num_hidden_layers, num_output)   # test/policy.jl:9
+        r = Ref{Ptr{Cvoid}}()
+        check(ccall((:ppo_policy_create, LIB), Int32, (Int32, Int32, Int32, Int32, Ref{Ptr{Cvoid}}),
+                    in_channels, hidden_channels, num_hidden_layers, num_output, r))
+        n = Ref{Int64}()
+        check(ccall((:ppo_policy_num_params, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), r[], n))
+        p = new(r[], n[])
+        finalizer(x -> ccall((:ppo_policy_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), p)
+    end
+end
+
+# Flux.params(policy) round trip: flat vector in Flux order (W1,b1,W2,b2,W3,b3), W [out,in] column-major
+set_params!(p::HipPolicy, flat::Vector{Float32}) =
+    check(ccall((:ppo_policy_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), p.h, flat))
+function get_params(p::HipPolicy)
+    flat = Vector{Float32}(undef, p.nparams)
+    check(ccall((:ppo_policy_get_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), p.h, flat)); flat
+end
+load_flux_chain!(p::HipPolicy, chain) = set_params!(p, vcat([vec(Float32.(x)) for x in Flux.params(chain)]...))
+
+struct StateData                      # test/quad_game_utilities.jl:17-20 (int8 rows + active-quad bits)
+    vertex_score::Array{Int8}; action_mask
+end
+
+mutable struct HipRollouts
+    h::Ptr{Cvoid}; env::Union{Nothing,HipVecEnv}
+    HipRollouts() = new(C_NULL, nothing)              # PPO.BufferRollouts()
+end
+function ensure!(r::HipRollouts, env::HipVecEnv, T)
+    if r.h == C_NULL
+        ref = Ref{Ptr{Cvoid}}()
+        check(ccall((:ppo_rollouts_create, LIB), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), env.h, T, ref))
+        r.h = ref[]; r.env = env
+        finalizer(x -> ccall((:ppo_rollouts_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), r)
+    end
+    r.h
+end
+
+struct HipAdam; h::Ptr{Cvoid}; eta::Float64; end      # member of a Flux.Optimiser-like iterable
+function HipAdam(p::HipPolicy, eta = 1e-3, beta = (0.9, 0.999), eps = 1e-8)
+    r = Ref{Ptr{Cvoid}}()
+    check(ccall((:ppo_adam_create, LIB), Int32, (Ptr{Cvoid}, Float64, Float64, Float64, Float64, Ref{Ptr{Cvoid}}),
+                p.h, eta, beta[1], beta[2], eps, r))
+    HipAdam(r[], eta)
+end
+
+# ---------------------------------------------------------------- env plugin methods  (:16-20)
+function PPO.state(env::HipVecEnv)
+    obs = Array{Int8}(undef, env.F, env.H, env.N); act = Vector{UInt32}(undef, env.N)   # column-major [F,H,N]
+    check(ccall((:ppo_env_get_state, LIB), Int32, (Ptr{Cvoid}, Ptr{Int8}, Ptr{UInt32}), env.h, obs, act))
+    StateData(obs, act)
+end
+function PPO.reward(env::HipVecEnv)
+    r = Vector{Float32}(undef, env.N)
+    check(ccall((:ppo_env_get_reward, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), env.h, r)); r
+end
+function PPO.is_terminal(env::HipVecEnv)
+    d = Vector{UInt8}(undef, env.N)
+    check(ccall((:ppo_env_get_terminal, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), env.h, d)); d .!= 0
+end
+PPO.reset!(env::HipVecEnv) = check(ccall((:ppo_env_reset, LIB), Int32, (Ptr{Cvoid},), env.h))
+PPO.step!(env::HipVecEnv, actions::AbstractVector{<:Integer}) =                      # 1-based -> 0-based
+    check(ccall((:ppo_env_step, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}), env.h, Int32.(actions .- 1)))
+
+# ---------------------------------------------------------------- policy / batching plugin methods  (:23-29)
+function PPO.batch_action_probabilities(p::HipPolicy, s::StateData)      # -> [A,B]
+    F, H, B = size(s.vertex_score, 1), size(s.vertex_score, 2), size(s.vertex_score, 3)
+    probs = Matrix{Float32}(undef, 4H, B)
+    check(ccall((:ppo_policy_forward, LIB), Int32, (Ptr{Cvoid}, Ptr{Int8}, Ptr{UInt32}, Int64, Int32, Ptr{Float32}),
+                p.h, s.vertex_score, UInt32.(s.action_mask), B, H, probs))
+    probs
+end
+PPO.action_probabilities(p::HipPolicy, s::StateData) = vec(PPO.batch_action_probabilities(p, s))
+PPO.number_of_actions_per_state(s::StateData) = 4 * size(s.vertex_score, 2)
+PPO.batch_advantage(s::StateData, returns) = returns                    # raw returns (no method exists upstream)
+
+# ---------------------------------------------------------------- path entry points
+function PPO.compute_returns(rewards::Vector{Float32}, terminal::AbstractVector{Bool}, discount, ::Val{:hip})
+    out = similar(rewards)
+    check(ccall((:ppo_compute_returns, LIB), Int32, (Ptr{Float32}, Ptr{UInt8}, Int64, Float64, Int32, Ptr{Float32}),
+                rewards, UInt8.(terminal), length(rewards), Float64(discount), discount isa Float32, out)); out
+end
+
+function PPO.collect_rollouts!(r::HipRollouts, env::HipVecEnv, p::HipPolicy, num_episodes, discount)
+    per_env = cld(num_episodes, env.N)
+    h = ensure!(r, env, per_env * 128)
+    check(ccall((:ppo_collect_rollouts_episodes, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Int32),
+                h, env.h, p.h, per_env, Float64(discount), discount isa Float32))
+end
+function Base.length(r::HipRollouts)
+    n = Ref{Int64}(); check(ccall((:ppo_rollouts_len, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), r.h, n)); n[]
+end
+PPO.construct_dataset(r::HipRollouts) = r              # dataset == non-owning view of the same handle
+
+function PPO.ppo_train!(p::HipPolicy, optimizer, r::HipRollouts, epsilon, batch_size, num_epochs, entropy_weight)
+    adam = first(optimizer)::HipAdam
+    ph, eh, lh = zeros(num_epochs), zeros(num_epochs), zeros(num_epochs)
+    check(ccall((:ppo_train, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int32, Float64, Int32, Ptr{Int64}, UInt64, Int32,
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                p.h, adam.h, r.h, epsilon, batch_size, num_epochs, entropy_weight, 0, C_NULL, rand(UInt64), 1,
+                C_NULL, C_NULL, ph, eh, lh))
+    for e in 1:num_epochs
+        PPO.@printf "EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e\n" e ph[e] eh[e] lh[e]
+    end
+    ph, eh, lh
+end
+# ppo_iterate!(policy, env, optimizer, ...) (src/train.jl:210-249) then works unchanged once
+# `BufferRollouts()` on its line 230 is replaced by `HipRollouts()` (or dispatched on the env type).
+
+end # module
