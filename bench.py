@@ -69,12 +69,17 @@ def cpu_baseline():
 
 
 def main():
+    global T_STEPS, EPOCHS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--t-steps", type=int, default=T_STEPS, help="profiling only: shorter rollout (flagged in the output)")
+    ap.add_argument("--epochs", type=int, default=EPOCHS, help="profiling only: fewer epochs (flagged in the output)")
     args = ap.parse_args()
+    reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
+    T_STEPS, EPOCHS = args.t_steps, args.epochs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,7 +170,7 @@ def main():
                                    "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)",
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world},
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced,
             "target_frac_of_1e6": value / 1e6,
         }
         if not args.no_cpu_baseline and world == 1:

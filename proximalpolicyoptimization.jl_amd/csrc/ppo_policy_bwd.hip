@@ -20,8 +20,11 @@
 // MFMA-bound: 2*32*(2*HID*HID + HID*F) flop per tile.
 #include "ppo_internal.h"
 #include "ppo_device.h"
+#include <cstdlib>
 
 struct BwdArgs {
+    unsigned long long* stamps;   // diagnostic build only (-DPPO_BWD_STAMP): [nwg][2 waves][6 phases]
+
     const int8_t* states; const int32_t* idx; int64_t B;
     const float4* act1; const float4* act2; const float4* dY;
     const float4* w2tp; const float4* w3p;
@@ -35,7 +38,8 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     constexpr int FP = ((F + 31) / 32) * 32;
     constexpr int NI = FP / 32;
     constexpr int LD = 33;                      // padded leading dimension (rows) of the LDS tiles
-    constexpr int XPT = F / 8;                  // state bytes staged per thread (threads 0..255)
+    constexpr int XDW = 32 * F / 4;             // dwords of one state
+    constexpr int XPD = (XDW + NTHR - 1) / NTHR;  // state dwords staged per thread
     constexpr int PF = (HID >= 256) ? 4 : 8;    // W2^T fragment groups in flight per wave (register budget)
     constexpr int S4 = HID / 8;                 // fragment groups of one W2^T tile
     static_assert(S4 % PF == 0 && NTHR >= 256 && NTHR >= HID, "shape");
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     float* sZ1 = sH2 + HID * LD;                // [HID][33]  dZ1^T
     float* sX = sZ1 + HID * LD;                 // [FP][33]   X^T (float)
     float* sDY = sX + FP * LD;                  // [32][4]
+    float* sW3 = sDY + 32 * 4;                  // [HID][4]   W3[:,f] per feature (staged once)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -64,59 +69,98 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     float db1 = 0.f, db2 = 0.f, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
 
     for (int i = tid; i < FP * LD; i += NTHR) sX[i] = 0.0f;     // rows i >= F stay zero (padding of dW1)
+    if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
+        const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
+    }
     __syncthreads();
 
-    const float4* w3_base = a.w3p + (size_t)(h * NT + w) * 16;
     const float4* w2t = a.w2tp + (size_t)w * S4 * 64 + lane;    // this wave's W2^T tile (k-tile w)
+    const unsigned fb = (unsigned)(32 * w + 4 * h);
 
+#ifdef PPO_BWD_STAMP
+    unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#define STAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
     for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        // per-lane LDS bases: element (feature 32w+4h+fo, row j) of each transposed tile.  `lb` is made opaque
+        // once per tile: everything derived from it is recomputed here (a few VALU ops) instead of being
+        // hoisted out of the tile loop as ~50 loop-invariant address registers that then spill to scratch
+        unsigned lb = fb * LD + j;
+        asm volatile("" : "+v"(lb));
+        float* const z2b = sZ2 + lb;
+        float* const h1b = sH1 + lb;
+        float* const h2b = sH2 + lb;
+        float* const z1b = sZ1 + lb;
+        const float* const w3b = sW3 + fb * 4;
         // ================= phase A: stage the tile (transposes through LDS)
-        const float4 dy = a.dY[(size_t)tile * 32 + j];
-        // keep the 16 W3 fragments out of the persistent register set: re-read them (L1-resident) per tile
-        const float4* w3 = w3_base;
-        asm volatile("" : "+v"(w3));
-        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        // all global loads of the tile are issued first (one exposed HBM latency), then transformed
+        float4 v2[4], v1[4];
         {
             const float4* s2 = a.act2 + ((size_t)tile * NT + w) * 4 * 64;
             const float4* s1 = a.act1 + ((size_t)tile * NT + w) * 4 * 64;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v2 = s2[q * 64 + lane];
-                const float4 v1 = s1[q * 64 + lane];
-                const float h2v[4] = {v2.x, v2.y, v2.z, v2.w};
-                const float h1v[4] = {v1.x, v1.y, v1.z, v1.w};
+            for (int q = 0; q < 4; ++q) { v2[q] = s2[q * 64 + lane]; v1[q] = s1[q * 64 + lane]; }
+        }
+        const float4 dy = a.dY[(size_t)tile * 32 + j];
+        uint32_t xd[XPD];
+        {
+            const uint32_t* xs = reinterpret_cast<const uint32_t*>(a.states + (size_t)a.idx[tile] * 32 * F);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * q + e;
-                    const int f = dfeat(w, r, h);
-                    const float4 ww = w3[r];
-                    const float dh = ww.x * dy.x + ww.y * dy.y + ww.z * dy.z + ww.w * dy.w;
-                    sZ2[f * LD + j] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
-                    sH2[f * LD + j] = h2v[e];
-                    sH1[f * LD + j] = h1v[e];
-                }
+            for (int i = 0; i < XPD; ++i) { const int d = tid + i * NTHR; xd[i] = d < XDW ? xs[d] : 0u; }
+        }
+#ifdef PPO_BWD_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(6);
+#endif
+        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        // feature of register r: 32w + 4h + (r&3) + 8(r>>2)  ->  one base per array + compile-time offsets
+        // (the offsets fold into the ds_* immediate field; no per-element address registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
+            const float h1v[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                constexpr int dummy = 0; (void)dummy;
+                const int fo = e + 8 * q;                          // feature offset inside the tile
+                const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
+                const float dh = ww.x * dy.x + ww.y * dy.y + ww.z * dy.z + ww.w * dy.w;
+                z2b[fo * LD] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                h2b[fo * LD] = h2v[e];
+                h1b[fo * LD] = h1v[e];
             }
         }
-        if (tid < 256) {
-            const int row = tid & 31, part = tid >> 5;            // 8 parts x F/8 features
-            const int8_t* xr = a.states + (size_t)a.idx[tile] * 32 * F + (size_t)row * F + part * XPT;
 #pragma unroll
-            for (int i = 0; i < XPT; ++i) sX[(part * XPT + i) * LD + row] = (float)xr[i];
+        for (int i = 0; i < XPD; ++i) {
+            const int d = tid + i * NTHR;                         // dword d = row*(F/4) + c : features 4c..4c+3
+            if (d < XDW) {
+                const int row = d / (F / 4), c = d % (F / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sX[(4 * c + e) * LD + row] = (float)(int)(int8_t)(xd[i] >> (8 * e));
+            }
         }
-        // start the W2^T stream before the barrier so the first groups land while the tile is staged
-        float4 ring[PF];
+        STAMP(0);
+        __syncthreads();
+        STAMP(1);
+        float4 ring[PF];                                          // W2^T stream (L2-resident)
 #pragma unroll
         for (int g = 0; g < PF; ++g) ring[g] = w2t[(size_t)g * 64];
-        __syncthreads();
 
         // ================= phase B: small VALU grads, dH1 = W2^T dZ2 (MFMA), dZ1 -> LDS
-        if (tid < HID) {
+        {   // small VALU grads, spread over all waves: lane (fl, hh) of wave w owns feature 32w+fl and rows
+            // [16hh, 16hh+16); the two halves are added once at the end of the kernel
+            const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
+            const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
+            const float* gy = sDY + 64 * h;
             float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const float z = sZ2[tid * LD + r];
-                const float hv = sH2[tid * LD + r];
-                const float4 y = *reinterpret_cast<const float4*>(&sDY[r * 4]);
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const float z = gz[r];
+                const float hv = gh[r];
+                const float4 y = *reinterpret_cast<const float4*>(gy + r * 4);
                 s2 += z; d0 += y.x * hv; d1 += y.y * hv; d2 += y.z * hv; d3 += y.w * hv;
             }
             db2 += s2; dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
@@ -130,16 +174,17 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
+            const float4* wn = w2t + (size_t)PF * 64;
 #pragma unroll 1
-            for (int s0 = 0; s0 < S4; s0 += PF) {
+            for (int s0 = 0; s0 < S4; s0 += PF, bz += 8 * PF * LD, wn += (size_t)PF * 64) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
-                    const int s4 = s0 + u;
                     const float4 ww = ring[u];
-                    ring[u] = w2t[(size_t)(s4 + PF) * 64];          // tail padding covers the over-read
+                    ring[u] = wn[(size_t)u * 64];                    // tail padding covers the over-read
                     float b[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = sZ2[(2 * (4 * s4 + e) + h) * LD + j];
+                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.x, b[0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.y, b[1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.z, b[2], acc, 0, 0, 0);
@@ -148,18 +193,21 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = dfeat(w, r, h);
-                const float hv = sH1[k * LD + j];
-                sZ1[k * LD + j] = acc[r] * (hv > 0.0f ? 1.0f : 0.01f);
+                const int fo = (r & 3) + 8 * (r >> 2);
+                const float hv = h1b[fo * LD];
+                z1b[fo * LD] = acc[r] * (hv > 0.0f ? 1.0f : 0.01f);
             }
         }
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
 
         // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
-        if (tid < HID) {
+        {
+            const float* g1 = sZ1 + (32 * w + j) * LD + 16 * h;
             float s1 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) s1 += sZ1[tid * LD + r];
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) s1 += g1[r];
             db1 += s1;
         }
         {
@@ -191,8 +239,14 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                     accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[it], accW1[it], 0, 0, 0);
             }
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
     }
+#ifdef PPO_BWD_STAMP
+    if (a.stamps && lane == 0 && (w == 0 || w == NT - 1))
+        for (int i = 0; i < 7; ++i) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 7 + i] = st_sum[i];
+#endif
 
     // ================= write the slab (fragment order; k_grad_reduce maps it to Flux order)
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
@@ -210,17 +264,32 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     for (int it = 0; it < NI; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = accW1[it][r];
-    if (tid < HID) {
-        sb1[tid] = db1; sb2[tid] = db2;
-        *reinterpret_cast<float4*>(&sw3[tid * 4]) = make_float4(dw3[0], dw3[1], dw3[2], dw3[3]);
+    {   // combine the two row halves (lanes l and l^32 own the same feature)
+        db1 += __shfl_xor(db1, 32); db2 += __shfl_xor(db2, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw3[i] += __shfl_xor(dw3[i], 32);
+        if (h == 0) {
+            const int f = 32 * w + j;
+            sb1[f] = db1; sb2[f] = db2;
+            *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(dw3[0], dw3[1], dw3[2], dw3[3]);
+        }
     }
     if (tid < 4) sb3[tid] = db3;
 }
 
+#ifdef PPO_BWD_STAMP
+unsigned long long* g_bwd_stamps = nullptr;
+extern "C" int32_t ppo_debug_bwd_stamps(unsigned long long* out) {
+    if (!g_bwd_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_bwd_stamps, 256 * 14 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 template <int F, int HID>
 static size_t bwd_lds_bytes() {
     constexpr int FP = ((F + 31) / 32) * 32;
-    return sizeof(float) * ((size_t)4 * HID * 33 + (size_t)FP * 33 + 32 * 4);
+    return sizeof(float) * ((size_t)4 * HID * 33 + (size_t)FP * 33 + 32 * 4 + (size_t)HID * 4);
 }
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
@@ -229,6 +298,10 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
     a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    a.stamps = nullptr;
+#ifdef PPO_BWD_STAMP
+    { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 14 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
+#endif
     const int nwg = (int)(B < 256 ? B : 256);
     p->nwg_bwd = nwg;
     ProfScope ps("k_policy_bwd");
