@@ -53,7 +53,10 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     float* sW3 = sDY + 32 * 4;                  // [HID][4]   W3[:,f] per feature (staged once)
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    // wave index as a provably wave-uniform scalar: everything derived from it (tile bases, global
+    // pointers) lives in SGPRs instead of per-lane 64-bit VGPR pairs
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
 
     f32x16 accW2[NT];
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     }
     __syncthreads();
 
-    const float4* w2t = a.w2tp + (size_t)w * S4 * 64 + lane;    // this wave's W2^T tile (k-tile w)
+    const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
+    const unsigned lo16 = (unsigned)lane * 16u;
     const unsigned fb = (unsigned)(32 * w + 4 * h);
 
 #ifdef PPO_BWD_STAMP
@@ -99,10 +103,14 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         // all global loads of the tile are issued first (one exposed HBM latency), then transformed
         float4 v2[4], v1[4];
         {
-            const float4* s2 = a.act2 + ((size_t)tile * NT + w) * 4 * 64;
-            const float4* s1 = a.act1 + ((size_t)tile * NT + w) * 4 * 64;
+            // scalar (SGPR) base + 32-bit per-lane byte offset -> saddr-form loads, no per-lane 64-bit pointers
+            const char* s2 = reinterpret_cast<const char*>(a.act2 + ((size_t)tile * NT + w) * 4 * 64);
+            const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)tile * NT + w) * 4 * 64);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v2[q] = s2[q * 64 + lane]; v1[q] = s1[q * 64 + lane]; }
+            for (int q = 0; q < 4; ++q) {
+                v2[q] = *reinterpret_cast<const float4*>(s2 + (lo16 + (unsigned)q * 1024u));
+                v1[q] = *reinterpret_cast<const float4*>(s1 + (lo16 + (unsigned)q * 1024u));
+            }
         }
         const float4 dy = a.dY[(size_t)tile * 32 + j];
         uint32_t xd[XPD];
@@ -147,11 +155,14 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         STAMP(1);
         float4 ring[PF];                                          // W2^T stream (L2-resident)
 #pragma unroll
-        for (int g = 0; g < PF; ++g) ring[g] = w2t[(size_t)g * 64];
+        for (int g = 0; g < PF; ++g) ring[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
 
         // ================= phase B: small VALU grads, dH1 = W2^T dZ2 (MFMA), dZ1 -> LDS
-        {   // small VALU grads, spread over all waves: lane (fl, hh) of wave w owns feature 32w+fl and rows
-            // [16hh, 16hh+16); the two halves are added once at the end of the kernel
+        // small VALU grads, spread over all waves: lane (fl, hh) of wave w owns feature 32w+fl and rows
+        // [16hh, 16hh+16); the two halves are added once at the end of the kernel.  The two waves that share
+        // a SIMD (w and w + NT/2) run them at opposite ends of the phase, so one wave's VALU/LDS work sits
+        // beside the other's MFMAs instead of both idling the matrix pipe together.
+        auto small_grads = [&]() {
             const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
             const float* gy = sDY + 64 * h;
@@ -164,24 +175,26 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                 s2 += z; d0 += y.x * hv; d1 += y.y * hv; d2 += y.z * hv; d3 += y.w * hv;
             }
             db2 += s2; dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
-        }
-        if (tid < 4) {
-            float s = 0.f;
-            for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
-            db3 += s;
-        }
+            if (tid < 4) {
+                float s = 0.f;
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                db3 += s;
+            }
+        };
+        const bool grads_first = (2 * w < NT);                    // wave-uniform (w is an SGPR)
+        if (grads_first) small_grads();
         {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
-            const float4* wn = w2t + (size_t)PF * 64;
+            const char* wn = w2t + (size_t)PF * 1024;                  // scalar pointer, advances per iteration
 #pragma unroll 1
-            for (int s0 = 0; s0 < S4; s0 += PF, bz += 8 * PF * LD, wn += (size_t)PF * 64) {
+            for (int s0 = 0; s0 < S4; s0 += PF, bz += 8 * PF * LD, wn += (size_t)PF * 1024) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     const float4 ww = ring[u];
-                    ring[u] = wn[(size_t)u * 64];                    // tail padding covers the over-read
+                    ring[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));   // tail padding covers the over-read
                     float b[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
@@ -198,6 +211,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                 z1b[fo * LD] = acc[r] * (hv > 0.0f ? 1.0f : 0.01f);
             }
         }
+        if (!grads_first) small_grads();
         STAMP(2);
         __syncthreads();
         STAMP(3);
