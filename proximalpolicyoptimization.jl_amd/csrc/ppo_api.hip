@@ -6,7 +6,6 @@
 #include <cstring>
 #include <mutex>
 
-int32_t launch_loss_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);
 
 // ---------------------------------------------------------------- globals
 static thread_local std::string g_err;
@@ -564,8 +563,7 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
     PPO_TRY(train_reserve(pol, B));
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew));
     PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
-    PPO_TRY(launch_grad_reduce(pol, B));
-    PPO_TRY(launch_loss_reduce(pol, B, B_global, ew));
+    PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
     pol->last_B = B; pol->last_entropy_weight = ew;
     return PPO_OK;
 }
@@ -601,7 +599,7 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
 
 int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol) {
     ARG_CHECK(opt && pol && opt->pol == pol, "update!: optimiser was created for another policy");
-    return launch_adam(opt);
+    return launch_adam(opt, nullptr);
 }
 
 int32_t ppo_last_losses(ppo_policy_t pol, double* ppoloss, double* entropyloss) {
@@ -627,10 +625,6 @@ __global__ void k_perm_index(const int32_t* __restrict__ index, const int64_t* _
     const int64_t p = perm[i];
     if (p < 0 || p >= len) { atomicOr(err, 16); out[i] = index[0]; return; }
     out[i] = index[p];
-}
-
-__global__ void k_copy_tail(const float* __restrict__ src, float* __restrict__ dst) {
-    if (threadIdx.x < 2) dst[threadIdx.x] = src[threadIdx.x];
 }
 
 int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon, int64_t batch_size,
@@ -670,8 +664,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
                 const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
                 if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }
             }
-            hipLaunchKernelGGL(k_copy_tail, dim3(1), dim3(64), 0, g_stream, pol->grad.p + pol->np, hist.p + 2 * b);
-            PPO_TRY(launch_adam(opt));                                              // Flux.update!  :81
+            PPO_TRY(launch_adam(opt, hist.p + 2 * b));                              // Flux.update!  :81 (+ loss history)
         }
         PPO_TRY(d2h(hh.data(), hist.p, (size_t)nb * 2));
         double sp = 0.0, se = 0.0;

@@ -143,8 +143,8 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                 int64_t B_global, double eps, double entropy_weight);
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
-int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B);
-int32_t launch_adam(ppo_adam_s* o);
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);
+int32_t launch_adam(ppo_adam_s* o, float* hist2_or_null);
 int32_t launch_categorical(const float* probs, const float* u, int64_t B, int64_t A, int32_t* actions, float* psel,
                            int32_t* err);
 int32_t launch_feistel_index(const int32_t* index_dev, int64_t len, uint64_t seed, uint32_t epoch, int32_t* out_dev);

@@ -20,8 +20,16 @@ static ParamLayout layout_of(const ppo_policy_s* p) {
 
 // ---------------------------------------------------------------- slab reduce
 // One thread per slab element (coalesced reads across slabs); fixed summation order.
+__device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
+                                  float* __restrict__ grad_tail);
+
 __global__ void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg, ParamLayout L,
-                              float* __restrict__ grad) {
+                              float* __restrict__ grad, const double* __restrict__ terms, int64_t B, double inv_Bg,
+                              double entropy_weight) {
+    if (blockIdx.x == gridDim.x - 1) {          // the extra last block reduces the per-sample loss terms
+        loss_reduce_block(terms, B, inv_Bg, entropy_weight, grad + L.np);
+        return;
+    }
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
     const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
@@ -59,8 +67,8 @@ __global__ void k_grad_reduce(const float* __restrict__ slabs, size_t slab_strid
 }
 
 // loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global
-__global__ void k_loss_reduce(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
-                              float* __restrict__ grad_tail) {
+__device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
+                                  float* __restrict__ grad_tail) {
     __shared__ double s0[256], s1[256];
     double a = 0.0, b = 0.0;
     for (int64_t i = threadIdx.x; i < B; i += 256) { a += terms[2 * i]; b += terms[2 * i + 1]; }
@@ -123,8 +131,9 @@ __global__ void k_pack_params(const float* __restrict__ params, ParamLayout L, P
 // arrays), Float32 stores; bias-correction powers tracked in Float64 on the host.
 __global__ void k_adam(float* __restrict__ params, const float* __restrict__ grad, float* __restrict__ m,
                        float* __restrict__ v, ParamLayout L, PackPtrs P, double eta, double beta1, double beta2,
-                       double eps, double bp1, double bp2) {
+                       double eps, double bp1, double bp2, float* __restrict__ hist2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (hist2 && i < 2) hist2[i] = grad[L.np + i];       // per-batch loss history (after any all-reduce)
     if (i >= L.np) return;
     const double gd = (double)grad[i];
     const float mn = (float)(beta1 * (double)m[i] + (1.0 - beta1) * gd);
@@ -159,34 +168,25 @@ int32_t launch_pack_params(ppo_policy_s* p) {
     return PPO_OK;
 }
 
-int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B) {
+// slab reduction + (one extra block) loss-term reduction in a single launch
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight) {
     ParamLayout L = layout_of(p);
     const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
-    {
-        ProfScope ps("k_grad_reduce");
-        hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppo_stream(),
-                           p->slabs.p, slab_floats(p->F, p->HID), p->nwg_bwd, L, p->grad.p);
-    }
-    (void)B;
+    ProfScope ps("k_grad_reduce");
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 255) / 256) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
+                       slab_floats(p->F, p->HID), p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
+                       entropy_weight);
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }
 
-int32_t launch_loss_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight) {
-    ParamLayout L = layout_of(p);
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, ppo_stream(), p->loss_terms.p, B, 1.0 / (double)B_global,
-                       entropy_weight, p->grad.p + L.np);
-    HIP_TRY(hipGetLastError());
-    return PPO_OK;
-}
-
-int32_t launch_adam(ppo_adam_s* o) {
+int32_t launch_adam(ppo_adam_s* o, float* hist2) {
     ppo_policy_s* p = o->pol;
     ParamLayout L = layout_of(p);
     ProfScope ps("k_adam");
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((L.np + 255) / 256)), dim3(256), 0, ppo_stream(), p->params.p, p->grad.p,
                        o->m.p, o->v.p, L, packs_of(p), o->eta, o->beta1, o->beta2, o->eps, o->beta_pow[0],
-                       o->beta_pow[1]);
+                       o->beta_pow[1], hist2);
     HIP_TRY(hipGetLastError());
     o->beta_pow[0] *= o->beta1;
     o->beta_pow[1] *= o->beta2;

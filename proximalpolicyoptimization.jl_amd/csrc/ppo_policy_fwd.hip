@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int S41 = F / 8;         // float4 groups of layer-1 k-steps
     constexpr int XB = F / 2;          // bytes of the state row held by one lane
     constexpr int XW = XB / 4;
-    constexpr int PF = 8;              // weight-fragment groups kept in flight per wave
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? 8 : 4;   // weight-fragment groups kept in flight per wave
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;           // half-edge row
@@ -70,21 +70,48 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
 
-    for (int64_t tile = wave; tile < a.B; tile += nwaves) {
-        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[tile] : tile;
-        const int8_t* st = a.states + (size_t)sid * 32 * F;
-        const uint32_t act = a.active[sid];
+    // the state rows of the NEXT tile are fetched while the current tile computes (the gather through idx is
+    // two dependent HBM round trips that one wave per SIMD cannot hide otherwise)
+    uint32_t xw[XW];
+    uint32_t act_next = 0;
+    int64_t sid_next = 0;
+    auto fetch_state = [&](int64_t t) {
+        const int64_t sidn = (MODE == 2) ? (int64_t)a.idx[t] : t;
+        const uint32_t* xr = reinterpret_cast<const uint32_t*>(a.states + (size_t)sidn * 32 * F + (size_t)j * F + (size_t)h * XB);
+#pragma unroll
+        for (int k = 0; k < XW; ++k) xw[k] = xr[k];
+        act_next = a.active[sidn];
+        sid_next = sidn;
+    };
+    constexpr bool PFX = (FwdCfg<F, HID>::WPS == 1);    // with two waves per SIMD the partner wave hides it instead
+    if (PFX && wave < a.B) fetch_state(wave);
 
+    for (int64_t tile = wave; tile < a.B; tile += nwaves) {
+        int64_t sid;
+        uint32_t act;
         // ---- state row -> B operands of layer 1: lane half 0 holds features [0,F/2), half 1 [F/2,F)
         float xf[XB];
-        {
-            const uint32_t* xr = reinterpret_cast<const uint32_t*>(st + (size_t)j * F + (size_t)h * XB);
+        if (PFX) {
+            sid = sid_next; act = act_next;
+#pragma unroll
+            for (int k = 0; k < XW; ++k) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[4 * k + i] = (float)(int)(int8_t)(xw[k] >> (8 * i));
+            }
+        } else {
+            sid = (MODE == 2) ? (int64_t)a.idx[tile] : tile;
+            act = a.active[sid];
+            const uint32_t* xr = reinterpret_cast<const uint32_t*>(a.states + (size_t)sid * 32 * F + (size_t)j * F + (size_t)h * XB);
 #pragma unroll
             for (int k = 0; k < XW; ++k) {
                 const uint32_t w = xr[k];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xf[4 * k + i] = (float)(int)(int8_t)(w >> (8 * i));
             }
+        }
+        if (PFX) {
+            const int64_t nt = tile + nwaves;
+            fetch_state(nt < a.B ? nt : tile);                  // unconditional: lands under the MFMA chains below
         }
 
         // ---- layer 1: H1^T[o-tile] = W1[o-tile,:] * X^T  (accumulator initialised with the bias)
