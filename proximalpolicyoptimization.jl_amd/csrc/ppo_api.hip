@@ -337,12 +337,12 @@ int32_t ppo_policy_forward(ppo_policy_t pol, const int8_t* states, const uint32_
                            float* probs) {
     ARG_CHECK(pol && states && active && probs, "batch_action_probabilities: null argument");
     ARG_CHECK(B >= 1, "batch_action_probabilities: empty batch");
-    if (H != 32) { ppo_set_error("policy_forward: H must be 32 half-edges (Q=8) in this build"); return PPO_ERR_UNSUPPORTED; }
+    if (H != 32 && H != 128) { ppo_set_error("policy_forward: H must be 32 (Q=8) or 128 (Q=32) half-edges in this build"); return PPO_ERR_UNSUPPORTED; }
     DevBuf<int8_t> s; DevBuf<uint32_t> a; DevBuf<float> p;
     const size_t ns = (size_t)B * H * pol->F;
     PPO_TRY(s.alloc(ns)); PPO_TRY(a.alloc(B)); PPO_TRY(p.alloc((size_t)B * H * 4));
     PPO_TRY(h2d(s.p, states, ns)); PPO_TRY(h2d(a.p, active, (size_t)B));
-    PPO_TRY(launch_policy_probs(pol, s.p, a.p, B, p.p));
+    PPO_TRY(launch_policy_probs(pol, s.p, a.p, B, H, p.p));
     return d2h(probs, p.p, (size_t)B * H * 4);
 }
 
@@ -423,7 +423,7 @@ static int32_t check_shapes(ppo_rollouts_s* ro, ppo_env_s* env, ppo_policy_s* po
     ARG_CHECK(ro && env && pol, "collect_rollouts!: null argument");
     ARG_CHECK(ro->N == env->N && ro->H == env->H && ro->F == env->F, "collect_rollouts!: rollouts were created for another env shape");
     ARG_CHECK(pol->F == env->F, "collect_rollouts!: policy input width != env feature count");
-    if (env->H != 32) { ppo_set_error("collect_rollouts!: H must be 32 half-edges (Q=8) in this build"); return PPO_ERR_UNSUPPORTED; }
+    if (env->H != 32 && env->H != 128) { ppo_set_error("collect_rollouts!: H must be 32 (Q=8) or 128 (Q=32) half-edges in this build"); return PPO_ERR_UNSUPPORTED; }
     return PPO_OK;
 }
 
@@ -546,6 +546,7 @@ int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, con
 }
 
 // ================================================================ training
+// B = number of 32-row tiles of the minibatch (states * H/32)
 static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
     if (B <= p->cap_tiles) return PPO_OK;
     const size_t NT = p->HID / 32;
@@ -560,7 +561,7 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
 // idx_dev: transition ids (already resolved through the dataset index)
 static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                     int64_t B_global, double eps, double ew) {
-    PPO_TRY(train_reserve(pol, B));
+    PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew));
     PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
     PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
@@ -582,10 +583,10 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
     ARG_CHECK(pol && ro && sample_idx, "step_batch!: null argument");
     ARG_CHECK(B >= 1 && B <= ro->len, "step_batch!: 1 <= batch_size <= num_data (src/train.jl:88)");
     ARG_CHECK(B_global >= B, "step_batch!: B_global < B");
-    ARG_CHECK(pol->F == ro->F && ro->H == 32, "step_batch!: shape mismatch");
+    ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "step_batch!: shape mismatch");
     if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
     for (int64_t i = 0; i < B; ++i) ARG_CHECK(sample_idx[i] >= 0 && sample_idx[i] < ro->len, "dataset index out of range (src/rollout_buffer.jl:105-106)");
-    PPO_TRY(train_reserve(pol, B));
+    PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
     DevBuf<int64_t> pos;
     PPO_TRY(pos.alloc(B));
     PPO_TRY(h2d(pos.p, sample_idx, (size_t)B));
@@ -636,9 +637,9 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
     ARG_CHECK(1 <= batch_size && batch_size <= len, "1 <= batch_size <= num_data (src/train.jl:88)");
     ARG_CHECK(num_epochs >= 0 && world >= 1, "ppo_train!: bad epochs/world");
     ARG_CHECK(world == 1 || allreduce, "ppo_train!: world > 1 needs an all-reduce hook");
-    ARG_CHECK(pol->F == ro->F && ro->H == 32, "ppo_train!: shape mismatch");
+    ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "ppo_train!: shape mismatch");
     if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
-    PPO_TRY(train_reserve(pol, batch_size));
+    PPO_TRY(train_reserve(pol, batch_size * (ro->H / 32)));
     const int64_t nb = (len + batch_size - 1) / batch_size;
     DevBuf<int32_t> order; DevBuf<int64_t> permd; DevBuf<float> hist;
     PPO_TRY(order.alloc(len));

@@ -137,7 +137,7 @@ int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out);
 
 int32_t launch_pack_params(ppo_policy_s* p);
 int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uint32_t* active_dev, int64_t B,
-                            float* probs_dev);
+                            int32_t H, float* probs_dev);
 int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
                               int32_t* actions_out, float* psel_out, float* full_probs_or_null);
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,

@@ -25,7 +25,8 @@
 struct BwdArgs {
     unsigned long long* stamps;   // diagnostic build only (-DPPO_BWD_STAMP): [nwg][2 waves][6 phases]
 
-    const int8_t* states; const int32_t* idx; int64_t B;
+    const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
+    int tps;                                                // tiles per state (H / 32)
     const float4* act1; const float4* act2; const float4* dY;
     const float4* w2tp; const float4* w3p;
     float* slabs; size_t slab_stride;
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         const float4 dy = a.dY[(size_t)tile * 32 + j];
         uint32_t xd[XPD];
         {
-            const uint32_t* xs = reinterpret_cast<const uint32_t*>(a.states + (size_t)a.idx[tile] * 32 * F);
+            const uint32_t* xs = reinterpret_cast<const uint32_t*>(
+                a.states + ((size_t)a.idx[tile / a.tps] * a.tps + (size_t)(tile % a.tps)) * 32 * F);
 #pragma unroll
             for (int i = 0; i < XPD; ++i) { const int d = tid + i * NTHR; xd[i] = d < XDW ? xs[d] : 0u; }
         }
@@ -308,7 +310,8 @@ static size_t bwd_lds_bytes() {
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
     BwdArgs a;
-    a.states = ro->states.p; a.idx = idx_dev; a.B = B;
+    a.tps = ro->H / 32;
+    a.states = ro->states.p; a.idx = idx_dev; a.B = B * a.tps;
     a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
@@ -316,7 +319,7 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
 #ifdef PPO_BWD_STAMP
     { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 14 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
 #endif
-    const int nwg = (int)(B < 256 ? B : 256);
+    const int nwg = (int)(a.B < 256 ? a.B : 256);
     p->nwg_bwd = nwg;
     ProfScope ps("k_policy_bwd");
 #define LAUNCH(FF, HH)                                                                                        \

@@ -415,3 +415,75 @@ def test_full_size_properties(P, orc):
     ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 4096, 1, 0.01, seed=1, verbose=False)
     assert np.isfinite(ph[0]) and np.isfinite(eh[0])
     assert np.isfinite(pol.params).all()
+
+
+# ---------------------------------------------------------------- BASELINE config 4 shape: Q=32 -> H=128, A=512
+def test_policy_forward_q32(P, orc):
+    rng = np.random.default_rng(128)
+    for HID in (128, 256):
+        pol = P.HipPolicy(72, HID, 2, 4, seed=5)
+        pol.params = pol.params + (rng.normal(size=pol.num_params) * 0.02).astype(np.float32)
+        B = 20
+        states = rng.integers(-3, 7, size=(B, 128, 72)).astype(np.int8)
+        active = rng.integers(1, 2**32, size=B, dtype=np.uint64).astype(np.uint32)
+        probs = P.batch_action_probabilities(pol, P.StateData(states, active)).T
+        assert probs.shape == (B, 512)
+        for b in range(B):
+            dev = orc.action_probabilities(pol.params, 72, HID, states[b], active[b], "dev")
+            assert np.array_equal(probs[b], dev)
+            ref = orc.action_probabilities(pol.params, 72, HID, states[b], active[b], "ref")
+            assert np.allclose(probs[b], ref, rtol=2e-5, atol=1e-8)
+            q = np.arange(512) // 16
+            assert np.all(probs[b][((int(active[b]) >> q) & 1) == 0] == 0.0)
+
+
+@pytest.mark.parametrize("HID", [128, 256])
+def test_rollout_and_gradient_q32(P, orc, HID):
+    """square_mesh-sized action space (Q=32 quads, 512 masked actions), variable-length episodes."""
+    N, T, max_actions = 12, 20, 9
+    env = P.HipVecEnv(num_envs=N, Q=32, max_actions=max_actions, seed=31)
+    pol = P.HipPolicy(72, HID, 2, 4, seed=8)
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, T, 1.0)
+    oenv = orc.Env(Q=32, max_actions=max_actions, N=N, seed=31)
+    oenv.reset()
+    ref = orc.collect_rollouts_tn(oenv, pol.params, HID, T, mode_dev=True)
+    st, act = ro.state_data
+    assert st.shape == (T, N, 128, 72)
+    assert np.array_equal(st, ref["states"]) and np.array_equal(act, ref["active"])
+    assert np.array_equal(ro.selected_actions - 1, ref["actions"])
+    assert np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
+    assert np.array_equal(ro.raw_rewards, ref["rewards"]) and np.array_equal(ro.terminal, ref["done"].astype(bool))
+    assert ref["done"].sum() >= N                          # episodes end early / at max_actions: variable length
+    ds = P.construct_dataset(ro)
+    sel = np.random.default_rng(1).choice(len(ds), size=30, replace=False) + 1
+    lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01)
+    a0 = (ro.selected_actions.reshape(-1)[sel - 1] - 1).astype(np.int32)
+    g64, olp, ole = orc.step_batch_grad_f64(pol.params, 72, HID, st.reshape(-1, 128, 72)[sel - 1], act.reshape(-1)[sel - 1],
+                                            a0, ro.selected_action_probabilities.reshape(-1)[sel - 1],
+                                            ro.rewards.reshape(-1)[sel - 1], 0.05, 0.01)
+    assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+    assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    opt = P.Optimiser(P.Adam(1e-4))
+    ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 64, 1, 0.01, seed=3, verbose=False)
+    assert np.isfinite(ph[0]) and np.isfinite(eh[0])
+
+
+def test_config4_size_properties(P, orc):
+    """BASELINE config 4 size: 8192 envs, Q=32 (A=512), masked actions, variable-length episodes."""
+    N, T = 8192, 16
+    env = P.HipVecEnv(num_envs=N, Q=32, max_actions=12, seed=4)
+    pol = P.HipPolicy(72, 128, 2, 4, seed=0)
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, T, 0.99)
+    a, p = ro.selected_actions, ro.selected_action_probabilities
+    st, act = ro.state_data
+    assert a.min() >= 1 and a.max() <= 512 and np.all(p > 0)
+    assert np.all((act >> ((a - 1) // 16).astype(np.uint32)) & 1)
+    assert np.array_equal(ro.rewards, orc.compute_returns_tn(ro.raw_rewards, ro.terminal, 0.99))
+    assert ro.terminal.sum() >= N
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        t, n = int(rng.integers(0, T)), int(rng.integers(0, N))
+        pr = orc.action_probabilities(pol.params, 72, 128, st[t, n], act[t, n], "dev")
+        assert p[t, n] == pr[a[t, n] - 1]
