@@ -91,16 +91,23 @@ def main():
     import ppo_amd as PPO
     dist = None
     torch = None
-    if world > 1:
+    # PPO_BENCH_FORCE_DIST=1 rehearses the whole distributed path (RCCL group, stream hand-over, all-reduce hook)
+    # with a single rank on a one-GPU box
+    use_dist = world > 1 or os.environ.get("PPO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" in os.environ:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
     PPO._lib.call("ppo_device_init", local_rank)
-    if world > 1:
+    if use_dist:
         PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
-    dp = PPO.DataParallel(rank, world)
+    dp = PPO.DataParallel(rank, world, force_hook=use_dist)
     env = PPO.HipVecEnv(num_envs=N_ENVS, Q=8, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
     pol = PPO.HipPolicy(F, HID, 2, 4, seed=0)
     opt = PPO.Optimiser(PPO.Adam(LR))
@@ -113,7 +120,7 @@ def main():
 
     def sync():
         PPO.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -126,7 +133,7 @@ def main():
         iteration(args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -154,7 +161,7 @@ def main():
         if k:
             roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": None}
-    elif world > 1:
+    elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
         PPO.synchronize()
 
@@ -181,7 +188,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

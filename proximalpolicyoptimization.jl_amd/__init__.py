@@ -647,7 +647,7 @@ def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entr
         pp = np.ascontiguousarray(np.asarray(perm, np.int64).reshape(num_epochs, n) - 1)
     ph, eh, lh = (np.zeros(num_epochs, np.float64) for _ in range(3))
     world, fn, keep = 1, _lib.ALLREDUCE_FN(0), None
-    if parallel is not None and parallel.world > 1:
+    if parallel is not None and (parallel.world > 1 or parallel.force_hook):
         world = parallel.world
         keep = parallel.make_hook(policy)
         fn = keep
@@ -698,8 +698,9 @@ class DataParallel:
     gradient buffer [num_params + 2] per optimiser step, through torch.distributed (backend "nccl" = RCCL
     over xGMI on MI355X; "gloo" for the CPU rehearsal of the host logic)."""
 
-    def __init__(self, rank=0, world=1):
+    def __init__(self, rank=0, world=1, force_hook=False):
         self.rank, self.world = int(rank), int(world)
+        self.force_hook = bool(force_hook)      # exercise the all-reduce hook even with one rank (tests)
 
     def env_shard(self, total_envs):
         """Contiguous shard [offset, offset+n) of this rank; RNG uses global env ids."""
@@ -716,8 +717,11 @@ class DataParallel:
 
     def make_hook(self, policy):
         import torch
+        # the engine must run on the stream torch orders its collectives against
+        call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
         ptr, n = policy.grad_buffer_dev()
         t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+        assert t.data_ptr() == ptr and t.numel() == n and t.dtype == torch.float32
 
         def hook(ctx, dev_ptr, n_floats):
             try:

@@ -98,6 +98,25 @@ class PPOError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64; if libppo_hip.so pulled
+    in the system runtime first, a later `import torch` would find no GPU (and torch.distributed/RCCL would be
+    unusable).  So when torch is installed its bundled runtime is loaded first (same SONAME, so libppo_hip.so
+    binds to it) -- torch itself is NOT imported.  PPO_HIP_RUNTIME=system opts out."""
+    if os.environ.get("PPO_HIP_RUNTIME", "torch") != "torch":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -105,6 +124,7 @@ def lib():
             raise ImportError(
                 "libppo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C proximalpolicyoptimization.jl_amd/csrc`. There is no CPU fallback." % SO_PATH)
+        _preload_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here == ABI drift

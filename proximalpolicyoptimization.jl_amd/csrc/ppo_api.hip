@@ -661,7 +661,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
         for (int64_t start = 0; start < len; start += batch_size, ++b) {           // :95-96 (last batch may be short)
             const int64_t B = (start + batch_size <= len) ? batch_size : (len - start);
             PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, B * world, epsilon, entropy_weight));
-            if (world > 1) {
+            if (allreduce) {                     // every rank of a data-parallel run; a world of 1 may pass it too
                 const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
                 if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }
             }

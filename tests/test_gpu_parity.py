@@ -487,3 +487,35 @@ def test_config4_size_properties(P, orc):
         t, n = int(rng.integers(0, T)), int(rng.integers(0, N))
         pr = orc.action_probabilities(pol.params, 72, 128, st[t, n], act[t, n], "dev")
         assert p[t, n] == pr[a[t, n] - 1]
+
+
+# ---------------------------------------------------------------- data-parallel plumbing on one GPU
+def test_allreduce_hook_single_rank_rccl(P, orc):
+    """One-rank RCCL group: the gradient buffer is aliased as a torch tensor and all-reduced on the engine's
+    stream every optimiser step.  With one rank the sum is the identity, so training must be bit-identical
+    to the hook-free run (validates aliasing, stream ordering and the C callback)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        res = []
+        for hook in (False, True):
+            env = P.HipVecEnv(num_envs=32, Q=8, max_actions=10, seed=2)
+            pol = P.HipPolicy(72, 128, 2, 4, seed=4)
+            ro = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro, env, pol, 8, 1.0)
+            ds = P.construct_dataset(ro)
+            opt = P.Optimiser(P.Adam(1e-3))
+            dp = P.DataParallel(0, 1, force_hook=hook)
+            perm = np.stack([np.random.default_rng(e).permutation(len(ds)) + 1 for e in range(2)])   # same order twice
+            ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 64, 2, 0.01, perm=perm, parallel=dp, verbose=False)
+            torch.cuda.synchronize()
+            res.append((pol.params.copy(), ph, eh))
+        assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    finally:
+        dist.destroy_process_group()
