@@ -157,6 +157,11 @@ def main():
             if n:
                 kernels[name] = {"avg_ms": round(ms / n, 4), "launches": n}
         PPO.profile_enable(False)
+        # K6 return scan at the config-5 size (65536 envs x 128 steps = 8.4 M transitions): HBM-bound, 9 B/transition
+        ms = PPO.profile_returns(128, 65536, GAMMA, 20)
+        gbs = 9.0 * 128 * 65536 / (ms * 1e-3) / 1e9
+        kernels["k_returns_tn@65536x128"] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
+                                             "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
         k = kernels.get("k_policy_bwd")
         if k:
             roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -188,8 +188,18 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
                   const int64_t* perm, uint64_t seed, int32_t world, ppo_allreduce_fn allreduce,
                   void* allreduce_ctx, double* ppo_hist, double* entropy_hist, double* lr_hist);
 
+/* average_returns(policy, env, num_trajectories) -> (mean, sample std [n-1]) of the UNdiscounted episode return
+ *                                                          src/evaluate.jl:1-25
+ * every resident env plays ceil(num_trajectories / N) whole episodes (reset! before each, stochastic policy);
+ * `scratch` is a rollout buffer created for this env (its contents are overwritten). */
+int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                            double* mean, double* std);
+
 /* timing of the dominant kernels of the last ppo_train / ppo_collect_rollouts call, measured with
  * HIP events on the engine's stream (bench.py roofline leg) */
+/* measurement helper: run the return scan `iters` times on device-resident synthetic [T,N] columns (no host
+ * copies in the timed region) and report the average kernel time (HIP events).  K6 roofline leg of bench.py. */
+int32_t ppo_profile_returns(int64_t T, int64_t N, double discount, int32_t iters, double* avg_ms);
 int32_t ppo_profile_enable(int32_t on);
 int32_t ppo_profile_get(const char* kernel_name, double* total_ms, int64_t* launches);
 

@@ -40,7 +40,7 @@ __all__ = [
     "compute_returns_tn", "gae_tn", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
     "simplified_ppo_clip", "get_linear_action_index", "ppo_loss_with_entropy", "categorical_sample", "step_batch_",
     "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
-    "device_count", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
+    "device_count", "average_returns", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
 ]
 
 
@@ -84,6 +84,13 @@ def synchronize():
 
 def profile_enable(on=True):
     call("ppo_profile_enable", int(bool(on)))
+
+
+def profile_returns(T, N, discount=1.0, iters=20):
+    """Average device time (ms) of the return scan on resident [T,N] columns (K6 roofline measurement)."""
+    ms = C.c_double(0)
+    call("ppo_profile_returns", int(T), int(N), float(discount), int(iters), C.byref(ms))
+    return ms.value
 
 
 def profile_get(name):
@@ -682,6 +689,17 @@ def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size,
         except PPOError:
             pass                         # no save_loss method exists anywhere in the reference (Appendix B)
     return loss
+
+
+def average_returns(policy, env, num_trajectories):
+    """PPO.average_returns(policy, env, num_trajectories) (src/evaluate.jl:18-25) -> (mean, std) of the
+    undiscounted episode return under the stochastic policy (std with the n-1 correction like Flux.std)."""
+    scratch = BufferRollouts()
+    per_env = -(-int(num_trajectories) // env.N)
+    h = scratch._ensure(env, per_env * env.max_actions)
+    m, s = C.c_double(0), C.c_double(0)
+    call("ppo_average_returns", policy._h, env._h, h, int(num_trajectories), C.byref(m), C.byref(s))
+    return m.value, s.value
 
 
 # ------------------------------------------------------------------ data parallel (one process per GPU)

@@ -137,6 +137,28 @@ int32_t ppo_profile_get(const char* kernel_name, double* total_ms, int64_t* laun
     return PPO_OK;
 }
 
+int32_t ppo_profile_returns(int64_t T, int64_t N, double discount, int32_t iters, double* avg_ms) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(T >= 1 && N >= 1 && iters >= 1 && avg_ms, "profile_returns: bad argument");
+    const size_t n = (size_t)T * N;
+    DevBuf<float> r, o; DevBuf<uint8_t> d;
+    PPO_TRY(r.alloc(n)); PPO_TRY(o.alloc(n)); PPO_TRY(d.alloc(n));
+    HIP_TRY(hipMemsetAsync(r.p, 0x3c, n * 4, g_stream));          // ~0.0115 everywhere
+    HIP_TRY(hipMemsetAsync(d.p, 0, n, g_stream));
+    PPO_TRY(launch_returns_tn(r.p, d.p, o.p, T, N, discount, 0)); // warm-up
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, g_stream));
+    for (int i = 0; i < iters; ++i) PPO_TRY(launch_returns_tn(r.p, d.p, o.p, T, N, discount, 0));
+    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    return PPO_OK;
+}
+
 // ================================================================ standalone ops
 int32_t ppo_compute_returns(const float* rewards, const uint8_t* terminal, int64_t n, double discount,
                             int32_t discount_is_f32, float* out) {
@@ -499,6 +521,41 @@ int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_poli
     PPO_TRY(h2d(ro->index.p, index.data(), index.size()));
     PPO_TRY(launch_returns_tn(ro->rewards.p, ro->done.p, ro->returns.p, T, N, discount, discount_is_f32));
     return ppo_env_check_errors(env, nullptr);
+}
+
+// average_returns (src/evaluate.jl:18-25): undiscounted return of each whole episode, then Flux.mean / Flux.std
+int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                            double* mean, double* std) {
+    ARG_CHECK(pol && env && scratch && mean && std && num_trajectories >= 1, "average_returns: bad argument");
+    const int64_t N = env->N;
+    const int64_t per_env = (num_trajectories + N - 1) / N;
+    PPO_TRY(ppo_collect_rollouts_episodes(scratch, env, pol, per_env, 1.0, 0));
+    const int64_t T = scratch->T;
+    std::vector<float> r((size_t)T * N);
+    std::vector<uint8_t> dn((size_t)T * N), va((size_t)T * N);
+    PPO_TRY(d2h(r.data(), scratch->rewards.p, r.size()));
+    PPO_TRY(d2h(dn.data(), scratch->done.p, dn.size()));
+    PPO_TRY(d2h(va.data(), scratch->valid.p, va.size()));
+    std::vector<double> rets;
+    rets.reserve((size_t)per_env * N);
+    for (int64_t n = 0; n < N; ++n) {
+        double acc = 0.0;
+        for (int64_t t = 0; t < T; ++t) {
+            const size_t i = (size_t)t * N + n;
+            if (!va[i]) continue;
+            acc += (double)r[i];                         // ret += reward(env)   src/evaluate.jl:13
+            if (dn[i]) { rets.push_back(acc); acc = 0.0; }
+        }
+    }
+    ARG_CHECK(!rets.empty(), "average_returns: no complete episode");
+    double m = 0.0;
+    for (double x : rets) m += x;
+    m /= (double)rets.size();
+    double v = 0.0;
+    for (double x : rets) v += (x - m) * (x - m);
+    *mean = m;
+    *std = rets.size() > 1 ? std::sqrt(v / (double)(rets.size() - 1)) : NAN;   // Flux.std: corrected (n-1)
+    return PPO_OK;
 }
 
 #define RO_GETTER(name, member, type, per)                                                     \

@@ -74,6 +74,70 @@ __global__ __launch_bounds__(256) void k_returns_tn(const float* __restrict__ r,
     }
 }
 
+
+// Wide variant for large N (N % 4 == 0): every lane owns 4 adjacent columns, so one wave row access is a full
+// 1 KiB float4 load/store and a 256 B done-flag load (4x fewer, 4x wider memory instructions: HBM streams at
+// DRAM-page granularity instead of 256 B snippets).  Same LDS-staged fp64 carry chain, same arithmetic.
+template <int F32MODE>
+__global__ __launch_bounds__(256) void k_returns_tn_x4(const float* __restrict__ r, const uint8_t* __restrict__ done,
+                                                       float* __restrict__ out, int64_t T, int64_t N, double discount) {
+    __shared__ double sCarry[RT_COLS * 4];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t n0 = ((int64_t)blockIdx.x * RT_COLS + lane) * 4;
+    const bool col_ok = n0 < N;                    // N % 4 == 0: all four columns valid together
+    const float gf = (float)discount;
+    const int64_t npass = (T + RT_CH * RT_WAVES - 1) / (RT_CH * RT_WAVES);
+    if (w == RT_WAVES - 1) { for (int c = 0; c < 4; ++c) sCarry[c * RT_COLS + lane] = 0.0; }
+    __syncthreads();
+    for (int64_t p = 0; p < npass; ++p) {
+        const int64_t base = T - (int64_t)RT_CH * RT_WAVES * (p + 1) + (int64_t)RT_CH * w;
+        float4 rr[RT_CH];
+        uint32_t dd[RT_CH];
+#pragma unroll
+        for (int i = 0; i < RT_CH; ++i) {
+            const int64_t t = base + i;
+            const bool ok = col_ok && t >= 0;
+            rr[i] = ok ? *reinterpret_cast<const float4*>(r + t * N + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dd[i] = ok ? *reinterpret_cast<const uint32_t*>(done + t * N + n0) : 0u;
+        }
+        for (int ww = RT_WAVES - 1; ww >= 0; --ww) {
+            if (w == ww) {
+                double v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = sCarry[c * RT_COLS + lane];
+#pragma unroll
+                for (int i = RT_CH - 1; i >= 0; --i) {
+                    const int64_t t = base + i;
+                    if (t >= 0) {
+                        const float rv[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
+                        float ov[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const bool dn = (dd[i] >> (8 * c)) & 0xffu;
+                            if (F32MODE) {
+                                float vf = dn ? 0.0f : (float)v[c];
+                                const float gv = gf * vf;
+                                vf = rv[c] + gv;
+                                v[c] = (double)vf; ov[c] = vf;
+                            } else {
+                                double vd = dn ? 0.0 : v[c];
+                                const double gv = discount * vd;
+                                vd = (double)rv[c] + gv;
+                                v[c] = vd; ov[c] = (float)vd;
+                            }
+                        }
+                        if (col_ok) *reinterpret_cast<float4*>(out + t * N + n0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sCarry[c * RT_COLS + lane] = v[c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Flat concatenated-episodes layout (the reference's own): each episode segment is scanned by
 // the thread that owns its last element, so the arithmetic is again the sequential recurrence.
 template <int F32MODE>
@@ -117,6 +181,13 @@ int32_t launch_returns_tn(const float* r, const uint8_t* done, float* out, int64
                           int f32mode) {
     if (T <= 0 || N <= 0) return PPO_OK;
     ProfScope ps("k_returns_tn");
+    if (N % 4 == 0 && N >= 16384) {                  // wide columns: 1 KiB per wave row
+        dim3 gridw((unsigned)((N / 4 + RT_COLS - 1) / RT_COLS));
+        if (f32mode) hipLaunchKernelGGL(k_returns_tn_x4<1>, gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
+        else hipLaunchKernelGGL(k_returns_tn_x4<0>, gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
+        HIP_TRY(hipGetLastError());
+        return PPO_OK;
+    }
     dim3 grid((unsigned)((N + RT_COLS - 1) / RT_COLS));
     if (f32mode) hipLaunchKernelGGL(k_returns_tn<1>, grid, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
     else hipLaunchKernelGGL(k_returns_tn<0>, grid, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);

@@ -21,7 +21,8 @@ def P(ppo):
 
 
 # ---------------------------------------------------------------- K6 returns / GAE
-@pytest.mark.parametrize("T,N", [(1, 1), (6, 1), (128, 1), (129, 65), (127, 64), (300, 200), (128, 4096)])
+@pytest.mark.parametrize("T,N", [(1, 1), (6, 1), (128, 1), (129, 65), (127, 64), (300, 200), (128, 4096),
+                                 (130, 16384), (33, 16388)])
 @pytest.mark.parametrize("gamma", [1.0, 0.99, np.float32(0.99)])
 def test_returns_tn_bitexact(P, orc, T, N, gamma):
     rng = np.random.default_rng(T * 1000 + N)
@@ -519,3 +520,26 @@ def test_allreduce_hook_single_rank_rccl(P, orc):
         assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     finally:
         dist.destroy_process_group()
+
+
+def test_average_returns_evaluator(P, orc):
+    """src/evaluate.jl:18-25 -- mean / sample-std of undiscounted episode returns, checked against an oracle replay."""
+    N, per_env = 6, 2
+    env = P.HipVecEnv(num_envs=N, Q=8, max_actions=7, seed=13)
+    pol = P.HipPolicy(72, 128, 2, 4, seed=3)
+    mean, std = P.average_returns(pol, env, N * per_env)
+    oenv = orc.Env(Q=8, max_actions=7, N=N, seed=13)
+    oenv.episode[:] = 1                                  # create() consumed episode 0 on the device side
+    rets = []
+    for n in range(N):
+        for ep in range(per_env):
+            oenv.reset_one(n)
+            acc = 0.0
+            while not oenv.done[n]:
+                p = orc.action_probabilities(pol.params, 72, 128, oenv.observe_one(n), oenv.active[n], "dev")
+                w = orc.philox([n, int(oenv.tick[n]), 0, 0], [13, 0])
+                a, err = orc.categorical_sample(p, orc.u01(w[0]))
+                oenv.step_one(n, a)
+                acc += float(oenv.reward[n])
+            rets.append(acc)
+    assert abs(mean - np.mean(rets)) < 1e-9 and abs(std - np.std(rets, ddof=1)) < 1e-9
