@@ -188,6 +188,20 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
                   const int64_t* perm, uint64_t seed, int32_t world, ppo_allreduce_fn allreduce,
                   void* allreduce_ctx, double* ppo_hist, double* entropy_hist, double* lr_hist);
 
+/* ---------------------------------------------------------------- out-of-core rollout store
+ * DiskRollouts / DiskDataset (src/rollouts_to_disk.jl:1-171, src/dataset.jl:1-82) for rollouts that should not
+ * stay resident: while ppo_collect_rollouts runs, every finished step [N] is copied device -> pinned host with
+ * hipMemcpyAsync on a copy stream (ordered by events, overlapping the next step's kernels) and a writer thread
+ * appends it to <dir>/rollout.bin; the returns column is appended when the scan has run (the reference rewrites
+ * trajectory.csv at the same point, :106-132).  One fixed-size binary shard instead of one BSON file per state;
+ * the reference's CSV + per-state BSON layout is produced by the host-side exporter for small runs.
+ * attach wipes and recreates <dir> like the DiskRollouts constructor (:7-13,23-45). */
+int32_t ppo_rollouts_attach_disk(ppo_rollouts_t ro, const char* dir, int32_t pinned_slots);
+int32_t ppo_rollouts_detach_disk(ppo_rollouts_t ro);
+/* DiskDataset: read <dir>/rollout.bin back into the (device) rollout buffer; shapes must match the env it was
+ * created for.  All transitions are valid afterwards. */
+int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir);
+
 /* average_returns(policy, env, num_trajectories) -> (mean, sample std [n-1]) of the UNdiscounted episode return
  *                                                          src/evaluate.jl:1-25
  * every resident env plays ceil(num_trajectories / N) whole episodes (reset! before each, stochastic policy);

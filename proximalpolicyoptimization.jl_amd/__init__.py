@@ -27,11 +27,15 @@ All compute runs in the HIP library; nothing here falls back to the CPU.
 """
 import ctypes as C
 import functools
+import os
+import shutil
 
 import numpy as np
 
 from . import _lib
 from ._lib import PPOError, call, lib
+from .disk import (DiskDataset, DiskRollouts, bson_decode_state, bson_encode_state, export_reference_layout,  # noqa: F401
+                   update_, write_returns_to_disk)
 
 __all__ = [
     "PPOError", "HipVecEnv", "HipPolicy", "Adam", "Optimiser", "StateData", "BufferRollouts", "BufferDataset",
@@ -40,7 +44,8 @@ __all__ = [
     "compute_returns_tn", "gae_tn", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
     "simplified_ppo_clip", "get_linear_action_index", "ppo_loss_with_entropy", "categorical_sample", "step_batch_",
     "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
-    "device_count", "average_returns", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
+    "device_count", "average_returns", "DiskRollouts", "DiskDataset", "update_", "write_returns_to_disk",
+    "export_reference_layout", "load_disk_rollouts", "bson_encode_state", "bson_decode_state", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
 ]
 
 
@@ -554,10 +559,18 @@ def _discount_args(discount):
 
 
 def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
-    """PPO.collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79).
-    The N resident envs each play ceil(num_episodes / N) whole episodes (reset! before each)."""
+    """PPO.collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79,
+    src/rollouts_to_disk.jl:134-147).  The N resident envs each play ceil(num_episodes / N) whole episodes
+    (reset! before each).  A DiskRollouts target additionally gets the reference's CSV + BSON layout."""
     if not isinstance(env, HipVecEnv) or not isinstance(policy, HipPolicy):
         _not_implemented("state")
+    if isinstance(rollouts, DiskRollouts):
+        print("\n\nCOLLECTING ROLLOUTS :")                              # src/rollouts_to_disk.jl:141
+        dev = BufferRollouts()
+        collect_rollouts_(dev, env, policy, num_episodes, discount)
+        rollouts._device = dev
+        export_reference_layout(rollouts, dev)
+        return
     if num_episodes < 1:
         raise PPOError(-1, "AssertionError: num_episodes must be >= 1")
     per_env = -(-int(num_episodes) // env.N)
@@ -566,8 +579,23 @@ def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     call("ppo_collect_rollouts_episodes", h, env._h, policy._h, per_env, g, f32)
 
 
-def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False):
-    """Vectorised fixed-T form: num_steps steps of all N envs with auto-reset (the throughput path)."""
+def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=4):
+    """Vectorised fixed-T form: num_steps steps of all N envs with auto-reset (the throughput path).
+    With a DiskRollouts target every finished step is streamed device -> pinned host -> <dir>/rollout.bin
+    while the next step runs (ppo_rollouts_attach_disk)."""
+    if isinstance(rollouts, DiskRollouts):
+        dev = BufferRollouts()
+        h = dev._ensure(env, int(num_steps))
+        # the constructor already wiped the directory; attach recreates it (same semantics) for the shard
+        call("ppo_rollouts_attach_disk", h, rollouts.state_data_directory.encode(), int(pinned_slots))
+        g, f32 = _discount_args(discount)
+        call("ppo_collect_rollouts", h, env._h, policy._h, int(num_steps), g, f32, 0)
+        call("ppo_rollouts_detach_disk", h)
+        rollouts._device = dev
+        rollouts.num_samples = len(dev)
+        with open(rollouts.trajectory_filename, "w", newline="") as f:          # attach wiped it: keep the header
+            f.write(",".join(DiskRollouts.FINAL) + "\n")
+        return
     h = rollouts._ensure(env, int(num_steps))
     g, f32 = _discount_args(discount)
     call("ppo_collect_rollouts", h, env._h, policy._h, int(num_steps), g, f32, int(bool(record_probs)))
@@ -613,7 +641,20 @@ class BufferDataset:
 
 
 def construct_dataset(rollouts):
+    """construct_dataset (src/rollout_buffer.jl:145-147, src/rollouts_to_disk.jl:169-171)."""
+    if isinstance(rollouts, DiskRollouts):
+        if rollouts._device is not None:
+            return BufferDataset(rollouts._device)       # columns are still resident: no reload needed
+        return DiskDataset(rollouts.state_data_directory)
     return BufferDataset(rollouts)
+
+
+def load_disk_rollouts(state_data_dir, env):
+    """DiskDataset over the engine's streaming shard: <dir>/rollout.bin -> device rollout buffer."""
+    ro = BufferRollouts()
+    h = ro._ensure(env, 1)
+    call("ppo_rollouts_load_disk", h, state_data_dir.encode())
+    return ro
 
 
 # ------------------------------------------------------------------ training
@@ -669,14 +710,16 @@ def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entr
 
 
 def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size, num_ppo_iterations, evaluator,
-                 epochs_per_iteration, discount, epsilon, entropy_weight, verbose=True):
-    """PPO.ppo_iterate! in-memory method (src/train.jl:210-249), positional argument order preserved."""
+                 epochs_per_iteration, discount, epsilon, entropy_weight, state_data_path=None, verbose=True):
+    """PPO.ppo_iterate! (src/train.jl:164-249), positional argument order preserved: 11 arguments = in-memory
+    method, a 12th `state_data_path` = the disk method (rollouts through DiskRollouts, directory removed at
+    the end, :198-201)."""
     loss = {"ppo": [], "entropy": [], "lr": []}
     for it in range(1, num_ppo_iterations + 1):
-        evaluator(policy, env, optimizer)                                                    # :226
+        evaluator(policy, env, optimizer)                                                    # :181,226
         if verbose:
             print("\nPPO ITERATION : %d" % it)
-        rollouts = BufferRollouts()                                                          # :230
+        rollouts = BufferRollouts() if state_data_path is None else DiskRollouts(state_data_path)   # :185,230
         collect_rollouts_(rollouts, env, policy, episodes_per_iteration, discount)
         dataset = construct_dataset(rollouts)
         p, e, lr = ppo_train_(policy, optimizer, dataset, epsilon, minibatch_size, epochs_per_iteration,
@@ -685,9 +728,13 @@ def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size,
         loss["entropy"] += e
         loss["lr"] += lr
         try:
-            save_loss(evaluator, loss)                                                       # :247
+            save_loss(evaluator, loss)                                                       # :196,247
         except PPOError:
             pass                         # no save_loss method exists anywhere in the reference (Appendix B)
+    if state_data_path is not None and os.path.isdir(state_data_path):
+        if verbose:
+            print("\n\nCLEARING DATA IN ROLLOUTS FOLDER :")                                 # :199
+        shutil.rmtree(state_data_path)
     return loss
 
 

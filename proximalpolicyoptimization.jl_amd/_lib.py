@@ -82,6 +82,9 @@ SIGNATURES = {
     "ppo_step_batch": [H, H, H, c_i64p, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p, c_f64p],
     "ppo_train": [H, H, H, C.c_double, C.c_int64, C.c_int32, C.c_double, C.c_int32, c_i64p, C.c_uint64, C.c_int32,
                   ALLREDUCE_FN, C.c_void_p, c_f64p, c_f64p, c_f64p],
+    "ppo_rollouts_attach_disk": [H, C.c_char_p, C.c_int32],
+    "ppo_rollouts_detach_disk": [H],
+    "ppo_rollouts_load_disk": [H, C.c_char_p],
     "ppo_average_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
     "ppo_profile_returns": [C.c_int64, C.c_int64, C.c_double, C.c_int32, c_f64p],
     "ppo_profile_enable": [C.c_int32],

@@ -459,6 +459,7 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     if (record_probs) PPO_TRY(ro->full_probs.alloc((size_t)T * N * env->A));
     // an env left terminal by a previous call starts a fresh episode (reset! before each episode)
     PPO_TRY(launch_env_reset(env, 1));
+    PPO_TRY(disk_sink_begin(ro, T));
     for (int64_t t = 0; t < T; ++t) {
         int8_t* st = ro->states.p + (size_t)t * srow;
         uint32_t* am = ro->active.p + (size_t)t * N;
@@ -466,11 +467,13 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
         PPO_TRY(launch_policy_rollout(pol, env, st, am, ro->actions.p + t * N, ro->p_sel.p + t * N,
                                       record_probs ? ro->full_probs.p + (size_t)t * N * env->A : nullptr));
         PPO_TRY(launch_env_step(env, ro->actions.p + t * N, ro->rewards.p + t * N, ro->done.p + t * N, nullptr, 1, 0));
+        PPO_TRY(disk_sink_step(ro, t));                 // out-of-core store: async D2H of step t on the copy stream
     }
     ro->T = T;
     PPO_TRY(set_index_all(ro));
     // compute_state_value!: returns overwrite the rewards column (src/rollout_buffer.jl:55-64)
     PPO_TRY(launch_returns_tn(ro->rewards.p, ro->done.p, ro->returns.p, T, N, discount, discount_is_f32));
+    PPO_TRY(disk_sink_finish(ro));
     return ppo_env_check_errors(env, nullptr);
 }
 

@@ -1,0 +1,232 @@
+// ppo_disk.hip -- out-of-core rollout store (DiskRollouts / DiskDataset: src/rollouts_to_disk.jl:1-171,
+// src/dataset.jl:1-82).  Device -> pinned host copies run on a dedicated copy stream, ordered behind the
+// producing kernels by events, so the PCIe transfer of step t overlaps the kernels of step t+1; a writer
+// thread drains the pinned ring into one append-only file.
+//
+// File format (little endian): header {magic "PPOR", u32 version=1, i64 N, i32 H, i32 F, i32 A, i32 pad, i64 T}
+// then T step records  [states N*H*F i8][active N u32][actions N i32][p_sel N f32][rewards N f32][done N u8]
+// then the returns column [T][N] f32 (written after compute_returns).
+#include "ppo_internal.h"
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <sys/stat.h>
+#include <dirent.h>
+#include <unistd.h>
+
+struct DiskHeader { char magic[4]; uint32_t version; int64_t N; int32_t H, F, A, pad; int64_t T; };
+
+struct DiskSink {
+    std::string dir;
+    int slots = 0;
+    size_t rec_bytes = 0;
+    std::vector<char*> pinned;            // ring of pinned host records
+    std::vector<hipEvent_t> produced;     // recorded on the compute stream after step t's kernels
+    std::vector<hipEvent_t> copied;       // recorded on the copy stream after the D2H of the slot
+    hipStream_t copy_stream = nullptr;
+    FILE* f = nullptr;
+    std::thread writer;
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t enq = 0, written = 0;         // records handed to the copy stream / written to the file
+    bool stop = false, failed = false;
+};
+
+static int rm_rf(const std::string& path) {
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) return 0;
+    if (S_ISDIR(st.st_mode)) {
+        DIR* d = opendir(path.c_str());
+        if (!d) return -1;
+        while (dirent* e = readdir(d)) {
+            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+            if (rm_rf(path + "/" + e->d_name) != 0) { closedir(d); return -1; }
+        }
+        closedir(d);
+        return rmdir(path.c_str());
+    }
+    return unlink(path.c_str());
+}
+
+static void writer_loop(DiskSink* s) {
+    for (;;) {
+        int64_t k;
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [&] { return s->stop || s->written < s->enq; });
+            if (s->written >= s->enq) { if (s->stop) return; continue; }
+            k = s->written;
+        }
+        const int slot = (int)(k % s->slots);
+        if (hipEventSynchronize(s->copied[slot]) != hipSuccess) s->failed = true;     // D2H of this record landed
+        if (!s->failed && fwrite(s->pinned[slot], 1, s->rec_bytes, s->f) != s->rec_bytes) s->failed = true;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->written = k + 1;
+        }
+        s->cv.notify_all();
+    }
+}
+
+void disk_sink_destroy(DiskSink* s) {
+    if (!s) return;
+    if (s->writer.joinable()) {
+        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+        s->cv.notify_all();
+        s->writer.join();
+    }
+    if (s->f) fclose(s->f);
+    for (char* p : s->pinned) if (p) (void)hipHostFree(p);
+    for (auto e : s->produced) (void)hipEventDestroy(e);
+    for (auto e : s->copied) (void)hipEventDestroy(e);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    delete s;
+}
+
+ppo_rollouts_s::~ppo_rollouts_s() { disk_sink_destroy(sink); sink = nullptr; }
+
+static size_t record_bytes(const ppo_rollouts_s* ro) {
+    const size_t N = (size_t)ro->N;
+    return N * ro->H * ro->F + N * 4 * 4 + N;
+}
+
+extern "C" int32_t ppo_rollouts_attach_disk(ppo_rollouts_t ro, const char* dir, int32_t pinned_slots) {
+    ARG_CHECK(ro && dir && dir[0], "DiskRollouts: bad argument");
+    ARG_CHECK(pinned_slots >= 2 && pinned_slots <= 64, "DiskRollouts: 2..64 pinned slots");
+    if (ro->sink) { disk_sink_destroy(ro->sink); ro->sink = nullptr; }
+    // prepare_state_data_directory: wipe and recreate (src/rollouts_to_disk.jl:7-13)
+    if (rm_rf(dir) != 0) { ppo_set_error(std::string("DiskRollouts: cannot clear ") + dir); return PPO_ERR_ARG; }
+    if (mkdir(dir, 0777) != 0) { ppo_set_error(std::string("DiskRollouts: cannot create ") + dir); return PPO_ERR_ARG; }
+    const std::string states = std::string(dir) + "/states";
+    if (mkdir(states.c_str(), 0777) != 0) { ppo_set_error("DiskRollouts: cannot create states/"); return PPO_ERR_ARG; }
+    DiskSink* s = new DiskSink();
+    s->dir = dir; s->slots = pinned_slots; s->rec_bytes = record_bytes(ro);
+    s->pinned.assign(pinned_slots, nullptr);
+    for (int i = 0; i < pinned_slots; ++i) {
+        if (hipHostMalloc((void**)&s->pinned[i], s->rec_bytes, hipHostMallocDefault) != hipSuccess) {
+            disk_sink_destroy(s); ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP;
+        }
+    }
+    s->produced.resize(pinned_slots); s->copied.resize(pinned_slots);
+    for (int i = 0; i < pinned_slots; ++i) {
+        (void)hipEventCreateWithFlags(&s->produced[i], hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming);
+    }
+    if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        disk_sink_destroy(s); ppo_set_error("DiskRollouts: copy stream"); return PPO_ERR_HIP;
+    }
+    ro->sink = s;
+    return PPO_OK;
+}
+
+extern "C" int32_t ppo_rollouts_detach_disk(ppo_rollouts_t ro) {
+    ARG_CHECK(ro, "null");
+    disk_sink_destroy(ro->sink);
+    ro->sink = nullptr;
+    return PPO_OK;
+}
+
+int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
+    DiskSink* s = ro->sink;
+    if (!s) return PPO_OK;
+    if (s->writer.joinable()) {                       // a previous collection: restart the file
+        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+        s->cv.notify_all();
+        s->writer.join();
+    }
+    if (s->f) { fclose(s->f); s->f = nullptr; }
+    s->enq = s->written = 0; s->stop = false; s->failed = false;
+    const std::string path = s->dir + "/rollout.bin";
+    s->f = fopen(path.c_str(), "wb");
+    if (!s->f) { ppo_set_error("DiskRollouts: cannot open " + path); return PPO_ERR_ARG; }
+    DiskHeader h;
+    memcpy(h.magic, "PPOR", 4); h.version = 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.pad = 0; h.T = T;
+    if (fwrite(&h, sizeof(h), 1, s->f) != 1) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
+    s->writer = std::thread(writer_loop, s);
+    return PPO_OK;
+}
+
+int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t) {
+    DiskSink* s = ro->sink;
+    if (!s) return PPO_OK;
+    const int slot = (int)(t % s->slots);
+    {   // the slot must have been written out before it is overwritten (back-pressure from the disk)
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->failed || s->written + s->slots > t; });
+    }
+    if (s->failed) { ppo_set_error("DiskRollouts: writer failed (disk full?)"); return PPO_ERR_ARG; }
+    const size_t N = (size_t)ro->N, sb = N * ro->H * ro->F;
+    HIP_TRY(hipEventRecord(s->produced[slot], ppo_stream()));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->produced[slot], 0));
+    char* dst = s->pinned[slot];
+    HIP_TRY(hipMemcpyAsync(dst, ro->states.p + (size_t)t * sb, sb, hipMemcpyDeviceToHost, s->copy_stream)); dst += sb;
+    HIP_TRY(hipMemcpyAsync(dst, ro->active.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
+    HIP_TRY(hipMemcpyAsync(dst, ro->actions.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
+    HIP_TRY(hipMemcpyAsync(dst, ro->p_sel.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
+    HIP_TRY(hipMemcpyAsync(dst, ro->rewards.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
+    HIP_TRY(hipMemcpyAsync(dst, ro->done.p + t * N, N, hipMemcpyDeviceToHost, s->copy_stream));
+    HIP_TRY(hipEventRecord(s->copied[slot], s->copy_stream));
+    { std::lock_guard<std::mutex> lk(s->mu); s->enq = t + 1; }
+    s->cv.notify_all();
+    return PPO_OK;
+}
+
+int32_t disk_sink_finish(ppo_rollouts_s* ro) {
+    DiskSink* s = ro->sink;
+    if (!s) return PPO_OK;
+    {   // drain the ring
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->failed || s->written >= s->enq; });
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    s->writer.join();
+    if (s->failed) { ppo_set_error("DiskRollouts: writer failed"); return PPO_ERR_ARG; }
+    // returns column (the reference rewrites trajectory.csv with the returns at this point)
+    const size_t n = (size_t)ro->T * ro->N;
+    std::vector<float> ret(n);
+    HIP_TRY(hipMemcpyAsync(ret.data(), ro->returns.p, n * 4, hipMemcpyDeviceToHost, ppo_stream()));
+    HIP_TRY(hipStreamSynchronize(ppo_stream()));
+    if (fwrite(ret.data(), 4, n, s->f) != n) { ppo_set_error("DiskRollouts: returns write failed"); return PPO_ERR_ARG; }
+    fclose(s->f); s->f = nullptr;
+    return PPO_OK;
+}
+
+extern "C" int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir) {
+    ARG_CHECK(ro && dir, "DiskDataset: bad argument");
+    const std::string path = std::string(dir) + "/rollout.bin";
+    FILE* f = fopen(path.c_str(), "rb");
+    ARG_CHECK(f != nullptr, "DiskDataset: trajectory file missing (src/dataset.jl:7)");
+    DiskHeader h;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "PPOR", 4) != 0 || h.version != 1) {
+        fclose(f); ppo_set_error("DiskDataset: bad header"); return PPO_ERR_ARG;
+    }
+    if (h.N != ro->N || h.H != ro->H || h.F != ro->F) { fclose(f); ppo_set_error("DiskDataset: shape mismatch"); return PPO_ERR_ARG; }
+    const int64_t T = h.T;
+    const size_t N = (size_t)ro->N, sb = N * ro->H * ro->F, rec = record_bytes(ro);
+    std::vector<char> buf(rec);
+    std::vector<int8_t> st((size_t)T * sb);
+    std::vector<uint32_t> act((size_t)T * N);
+    std::vector<int32_t> a0((size_t)T * N);
+    std::vector<float> ps((size_t)T * N), rw((size_t)T * N), ret((size_t)T * N);
+    std::vector<uint8_t> dn((size_t)T * N);
+    for (int64_t t = 0; t < T; ++t) {
+        if (fread(buf.data(), 1, rec, f) != rec) { fclose(f); ppo_set_error("DiskDataset: truncated file"); return PPO_ERR_ARG; }
+        const char* p = buf.data();
+        memcpy(st.data() + (size_t)t * sb, p, sb); p += sb;
+        memcpy(act.data() + t * N, p, N * 4); p += N * 4;
+        memcpy(a0.data() + t * N, p, N * 4); p += N * 4;
+        memcpy(ps.data() + t * N, p, N * 4); p += N * 4;
+        memcpy(rw.data() + t * N, p, N * 4); p += N * 4;
+        memcpy(dn.data() + t * N, p, N);
+    }
+    const bool have_ret = fread(ret.data(), 4, (size_t)T * N, f) == (size_t)T * N;
+    fclose(f);
+    ARG_CHECK(have_ret, "DiskDataset: returns column missing (collection did not finish)");
+    PPO_TRY(ppo_rollouts_set(ro, T, st.data(), act.data(), a0.data(), ps.data(), ret.data(), dn.data()));
+    HIP_TRY(hipMemcpyAsync(ro->rewards.p, rw.data(), (size_t)T * N * 4, hipMemcpyHostToDevice, ppo_stream()));
+    HIP_TRY(hipStreamSynchronize(ppo_stream()));
+    return PPO_OK;
+}

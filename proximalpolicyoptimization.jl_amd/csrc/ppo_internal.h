@@ -100,6 +100,8 @@ struct ppo_adam_s {
     DevBuf<float> m, v;
 };
 
+struct DiskSink;   // ppo_disk.hip
+
 struct ppo_rollouts_s {
     int64_t N, capT, T;    // T = steps currently held
     int32_t H, F, A;
@@ -115,7 +117,15 @@ struct ppo_rollouts_s {
     DevBuf<int32_t> index;     // [len] transition ids in dataset order
     DevBuf<float> full_probs;  // [T][N][A] optional
     bool all_valid = true;
+    DiskSink* sink = nullptr;  // optional out-of-core store (ppo_rollouts_attach_disk)
+    ~ppo_rollouts_s();
 };
+
+// out-of-core store hooks used by ppo_collect_rollouts (ppo_disk.hip)
+int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T);
+int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t);       // after the kernels of step t were enqueued
+int32_t disk_sink_finish(ppo_rollouts_s* ro);                // after the return scan: appends returns, flushes
+void disk_sink_destroy(DiskSink* s);
 
 // ---------------------------------------------------------------- packed layout sizes
 static inline size_t slab_floats(int F, int HID) {

@@ -543,3 +543,62 @@ def test_average_returns_evaluator(P, orc):
                 acc += float(oenv.reward[n])
             rets.append(acc)
     assert abs(mean - np.mean(rets)) < 1e-9 and abs(std - np.std(rets, ddof=1)) < 1e-9
+
+
+# ---------------------------------------------------------------- disk rollout store (config 5 / src/rollouts_to_disk.jl)
+def test_write_returns_to_disk_reproduces_reference_csv(P, golden_dir, tmp_path):
+    """test/write_action_history.jl + output/trajectory.csv: six update! calls then write_returns_to_disk(.,1.0)
+    must give the reference's own trajectory.csv byte for byte."""
+    d = P.DiskRollouts(str(tmp_path / "output"))
+    for k in range(6):
+        P.update_(d, np.array([1, 2, 3, 4, 5], np.int64), 0.5, 4, 1, k == 5)
+    P.write_returns_to_disk(d, 1.0)
+    want = open(os.path.join(golden_dir, "trajectory.csv")).read().replace("\r\n", "\n")
+    assert open(d.trajectory_filename).read() == want
+    assert open(os.path.join(d.state_data_directory, "states", "sample_6.bson"), "rb").read() == \
+        open(os.path.join(golden_dir, "sample_1.bson"), "rb").read()
+    ds = P.DiskDataset(d.state_data_directory)
+    assert len(ds) == 6 and ds[1]["returns"] == 6.0 and ds[6]["returns"] == 1.0
+
+
+def test_streamed_disk_rollouts_roundtrip(P, orc, tmp_path):
+    """Steps are streamed device -> pinned host -> rollout.bin while collection runs; the shard read back through
+    ppo_rollouts_load_disk must reproduce every column, and training from it must match training from memory."""
+    N, T = 48, 12
+    res = {}
+    for mode in ("memory", "disk"):
+        env = P.HipVecEnv(num_envs=N, Q=8, max_actions=9, seed=17)
+        pol = P.HipPolicy(72, 128, 2, 4, seed=6)
+        if mode == "memory":
+            ro = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro, env, pol, T, 0.99)
+        else:
+            disk = P.DiskRollouts(str(tmp_path / "store"))
+            P.collect_rollouts_steps_(disk, env, pol, T, 0.99, pinned_slots=2)      # 2 slots: exercises back-pressure
+            assert os.path.getsize(os.path.join(disk.state_data_directory, "rollout.bin")) == \
+                40 + T * (N * 32 * 72 + N * 17) + T * N * 4          # header, T step records, returns column
+            assert len(disk) == N * T
+            ro = P.load_disk_rollouts(disk.state_data_directory, env)               # DiskDataset path
+        st, act = ro.state_data
+        ds = P.construct_dataset(ro)
+        opt = P.Optimiser(P.Adam(1e-3))
+        perm = np.stack([np.random.default_rng(3).permutation(len(ds)) + 1])
+        ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 128, 1, 0.01, perm=perm, verbose=False)
+        res[mode] = (st, act, ro.selected_actions, ro.selected_action_probabilities, ro.rewards, ro.raw_rewards,
+                     ro.terminal, pol.params, ph, eh)
+    for a, b in zip(res["memory"], res["disk"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_ppo_iterate_disk_method(P, tmp_path):
+    """ppo_iterate! 12-argument method (src/train.jl:164-202): rollouts through DiskRollouts, folder cleared."""
+    env = P.HipVecEnv(num_envs=4, Q=8, max_actions=6, seed=1)
+    pol = P.HipPolicy(72, 128, 2, 4, seed=0)
+    opt = P.Optimiser(P.Adam(1e-4))
+    calls = []
+    path = str(tmp_path / "iter_store")
+    loss = P.ppo_iterate_(pol, env, opt, 8, 8, 2, lambda p, e, o: calls.append(1), 1, 1.0, 0.05, 0.01, path,
+                          verbose=False)
+    assert len(calls) == 2 and len(loss["ppo"]) == 2 and not os.path.exists(path)
+    loss2 = P.ppo_iterate_(pol, env, opt, 8, 8, 1, lambda p, e, o: None, 2, 1.0, 0.05, 0.01, verbose=False)
+    assert len(loss2["entropy"]) == 2 and loss2["lr"] == [1e-4, 1e-4]
