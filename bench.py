@@ -164,8 +164,21 @@ def main():
                                              "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
         k = kernels.get("k_policy_bwd")
         if k:
+            # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
+            # inside this process); null when the file is absent
+            traffic, tsrc = None, None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = pm["kernels"]["k_policy_bwd<72, 256>"]["hbm_bytes"]
+                tsrc = "profiles/r01_pmc_traffic.json (" + pm["source"] + ")"
+            except Exception:
+                pass
             roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": k["frac"], "traffic": None}
+                    "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "traffic_source": tsrc,
+                    "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
+                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (2 * HID * 32 * 4 + 32 * F + 32 * 16) + 256 * 4 *
+                    (HID * HID + HID * 96 + HID * 6 + 4)}
     elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
         PPO.synchronize()
