@@ -3,7 +3,13 @@
 import csv, glob, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + "/*/*/*counter_collection.csv"):
+import os
+files = []
+for d in glob.glob(root + "/*/*/"):      # newest file per pass directory (gpurun_out accumulates older runs)
+    c = sorted(glob.glob(d + "*counter_collection.csv"), key=os.path.getmtime)
+    if c:
+        files.append(c[-1])
+for f in files:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0][:40]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

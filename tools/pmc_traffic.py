@@ -5,7 +5,13 @@ stream -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Both
 import csv, glob, json, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + "/*/*/*counter_collection.csv"):
+import os
+files = []
+for d in glob.glob(root + "/*/*/"):      # newest file per pass directory (gpurun_out accumulates older runs)
+    c = sorted(glob.glob(d + "*counter_collection.csv"), key=os.path.getmtime)
+    if c:
+        files.append(c[-1])
+for f in files:
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
