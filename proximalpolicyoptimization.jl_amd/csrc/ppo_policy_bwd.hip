@@ -82,7 +82,37 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
     const unsigned lo16 = (unsigned)lane * 16u;
     const unsigned fb = (unsigned)(32 * w + 4 * h);
+    // LDS-DMA prefetch of the NEXT tile's layer-2 fragments (4 x 1 KiB, lane-linear) into this wave's own sH2
+    // slice: rows [32w, 32w+32) of sH2 are written (phase A) and read (small_grads) by wave w only, so once the
+    // wave's small_grads are done the slice is free until phase A of the next tile.  No registers involved.
+    float* const h2slice = sH2 + (size_t)(32 * w) * LD;
+    auto dma_next_act2 = [&](int64_t t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of the slice have returned
+        const float4* src = a.act2 + ((size_t)t * NT + w) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
+                                             (__attribute__((address_space(3))) void*)(h2slice + q * 256), 16, 0, 0);
+    };
+    if ((int64_t)blockIdx.x < a.B) dma_next_act2(blockIdx.x);
 
+    float4 v1[4], dy;
+    uint32_t xd[XPD];
+    auto issue_tile_loads = [&](int64_t t, int sidx) {      // sidx: transition id of tile t's state (wave-uniform)
+        // scalar (SGPR) base + 32-bit per-lane byte offset -> saddr-form loads, no per-lane 64-bit pointers
+        const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)t * NT + w) * 4 * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v1[q] = *reinterpret_cast<const float4*>(s1 + (lo16 + (unsigned)q * 1024u));
+        dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+        const char* xs = reinterpret_cast<const char*>(a.states + ((size_t)sidx * a.tps + (size_t)(t % a.tps)) * 32 * F);
+#pragma unroll
+        for (int i = 0; i < XPD; ++i) {
+            const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
+            xd[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+        }
+    };
+    if ((int64_t)blockIdx.x < a.B)
+        issue_tile_loads(blockIdx.x, __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
 #ifdef PPO_BWD_STAMP
     unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #define STAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
@@ -101,25 +131,16 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         float* const z1b = sZ1 + lb;
         const float* const w3b = sW3 + fb * 4;
         // ================= phase A: stage the tile (transposes through LDS)
-        // all global loads of the tile are issued first (one exposed HBM latency), then transformed
-        float4 v2[4], v1[4];
+        // Nothing is fetched here any more: the layer-1 fragments, dY and the state dwords were issued into
+        // registers at the top of phase D of the previous tile (v1/dy/xd), the layer-2 fragments came by LDS-DMA.
+        float4 v2[4];
         {
-            // scalar (SGPR) base + 32-bit per-lane byte offset -> saddr-form loads, no per-lane 64-bit pointers
-            const char* s2 = reinterpret_cast<const char*>(a.act2 + ((size_t)tile * NT + w) * 4 * 64);
-            const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)tile * NT + w) * 4 * 64);
+            // wait for everything this wave has in flight (its DMA is the oldest), read the raw 4 KiB of layer-2
+            // fragments out of the slice, and only then overwrite the slice with the transposed tile below
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v2[q] = *reinterpret_cast<const float4*>(s2 + (lo16 + (unsigned)q * 1024u));
-                v1[q] = *reinterpret_cast<const float4*>(s1 + (lo16 + (unsigned)q * 1024u));
-            }
-        }
-        const float4 dy = a.dY[(size_t)tile * 32 + j];
-        uint32_t xd[XPD];
-        {
-            const uint32_t* xs = reinterpret_cast<const uint32_t*>(
-                a.states + ((size_t)a.idx[tile / a.tps] * a.tps + (size_t)(tile % a.tps)) * 32 * F);
-#pragma unroll
-            for (int i = 0; i < XPD; ++i) { const int d = tid + i * NTHR; xd[i] = d < XDW ? xs[d] : 0u; }
+            for (int q = 0; q < 4; ++q) v2[q] = *reinterpret_cast<const float4*>(h2slice + q * 256 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #ifdef PPO_BWD_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -184,7 +205,8 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             }
         };
         const bool grads_first = (2 * w < NT);                    // wave-uniform (w is an SGPR)
-        if (grads_first) small_grads();
+        const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;    // harmless re-load on the last tile
+        if (grads_first) { small_grads(); dma_next_act2(ntile); }
         {
             f32x16 acc;
 #pragma unroll
@@ -217,8 +239,10 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         STAMP(2);
         __syncthreads();
         STAMP(3);
+        if (!grads_first) dma_next_act2(ntile);                   // after the barrier: __syncthreads drains vmcnt
 
         // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
+        const int nidx = a.idx[ntile / a.tps];                    // next tile's transition id, consumed in phase D
         {
             const float* g1 = sZ1 + (32 * w + j) * LD + 16 * h;
             float s1 = 0.f;
@@ -241,6 +265,10 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             }
         }
         // ================= phase D: dW1[k,i] += sum_rows dZ1[k,row] * X[i,row]     (wave w: k-tile w)
+        // register pressure is lowest here: the NEXT tile's layer-1 fragments, dY and state dwords are issued
+        // now (22 registers) and land under this phase's MFMAs and the barrier; consumed in phase A.
+        // Unconditional (a harmless re-load on the last tile): no phi, so the staging registers live D..A only.
+        issue_tile_loads(ntile, __builtin_amdgcn_readfirstlane(nidx));
         {
             const float* pa = sZ1 + (32 * w + j) * LD + h;
             const float* pb = sX + j * LD + h;

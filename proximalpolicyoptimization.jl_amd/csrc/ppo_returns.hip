@@ -75,67 +75,92 @@ __global__ __launch_bounds__(256) void k_returns_tn(const float* __restrict__ r,
 }
 
 
-// Wide variant for large N (N % 4 == 0): every lane owns 4 adjacent columns, so one wave row access is a full
-// 1 KiB float4 load/store and a 256 B done-flag load (4x fewer, 4x wider memory instructions: HBM streams at
-// DRAM-page granularity instead of 256 B snippets).  Same LDS-staged fp64 carry chain, same arithmetic.
+// Wide variant for large N (N % 4 == 0), LDS-staged.  A workgroup owns 256 adjacent columns.  Per pass of
+// RW_ROWS time rows: (1) every wave loads its share of the rows with full 1 KiB float4 row accesses (256 B for
+// the done flags) and parks them in an LDS tile [rows][256]; (2) after a barrier wave w scans columns
+// [64w, 64w+64) of the tile -- one column per lane, the exact sequential fp64 recurrence, carry kept in a
+// register across passes, NO cross-wave dependency -- writing the returns back into the tile; (3) after a second
+// barrier the tile leaves with wide stores.  HBM sees only wide, fully used accesses; the scan reads the tile
+// row by row (conflict-free).  Two tiles are ping-ponged so the loads of pass p+1 are in flight during pass p.
+#define RW_ROWS 32
+#define RW_COLS 256
 template <int F32MODE>
 __global__ __launch_bounds__(256) void k_returns_tn_x4(const float* __restrict__ r, const uint8_t* __restrict__ done,
                                                        float* __restrict__ out, int64_t T, int64_t N, double discount) {
-    __shared__ double sCarry[RT_COLS * 4];
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int64_t n0 = ((int64_t)blockIdx.x * RT_COLS + lane) * 4;
-    const bool col_ok = n0 < N;                    // N % 4 == 0: all four columns valid together
+    __shared__ __attribute__((aligned(16))) float sR[2][RW_ROWS][RW_COLS];        // 64 KiB
+    __shared__ __attribute__((aligned(16))) uint8_t sD[2][RW_ROWS][RW_COLS];      // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * RW_COLS;           // first column of the workgroup
+    const int64_t cl = c0 + lane * 4;                           // this lane's 4 columns for the wide accesses
+    const bool wide_ok = cl < N;                                // N % 4 == 0
+    const int64_t cs = c0 + 64 * w + lane;                      // this lane's scan column
     const float gf = (float)discount;
-    const int64_t npass = (T + RT_CH * RT_WAVES - 1) / (RT_CH * RT_WAVES);
-    if (w == RT_WAVES - 1) { for (int c = 0; c < 4; ++c) sCarry[c * RT_COLS + lane] = 0.0; }
+    const int64_t npass = (T + RW_ROWS - 1) / RW_ROWS;
+    double v = 0.0;                                             // running value of column cs (fp64 or exact fp32 value)
+    constexpr int RPW = RW_ROWS / 4;                            // rows loaded / stored per wave per pass
+
+    float4 rv[RPW];
+    uint32_t dv[RPW];
+    auto load_regs = [&](int64_t p) {                          // rows [T - RW_ROWS*(p+1), +RW_ROWS), wave w: RPW of them
+        const int64_t base = T - (int64_t)RW_ROWS * (p + 1);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int64_t t = base + w * RPW + i;
+            rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[i] = 0u;
+            if (wide_ok && t >= 0) {
+                rv[i] = *reinterpret_cast<const float4*>(r + t * N + cl);
+                dv[i] = *reinterpret_cast<const uint32_t*>(done + t * N + cl);
+            }
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            *reinterpret_cast<float4*>(&sR[buf][w * RPW + i][lane * 4]) = rv[i];
+            *reinterpret_cast<uint32_t*>(&sD[buf][w * RPW + i][lane * 4]) = dv[i];
+        }
+    };
+
+    load_regs(0);
+    park(0);
     __syncthreads();
     for (int64_t p = 0; p < npass; ++p) {
-        const int64_t base = T - (int64_t)RT_CH * RT_WAVES * (p + 1) + (int64_t)RT_CH * w;
-        float4 rr[RT_CH];
-        uint32_t dd[RT_CH];
-#pragma unroll
-        for (int i = 0; i < RT_CH; ++i) {
-            const int64_t t = base + i;
-            const bool ok = col_ok && t >= 0;
-            rr[i] = ok ? *reinterpret_cast<const float4*>(r + t * N + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dd[i] = ok ? *reinterpret_cast<const uint32_t*>(done + t * N + n0) : 0u;
-        }
-        for (int ww = RT_WAVES - 1; ww >= 0; --ww) {
-            if (w == ww) {
-                double v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = sCarry[c * RT_COLS + lane];
-#pragma unroll
-                for (int i = RT_CH - 1; i >= 0; --i) {
-                    const int64_t t = base + i;
-                    if (t >= 0) {
-                        const float rv[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
-                        float ov[4];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const bool dn = (dd[i] >> (8 * c)) & 0xffu;
-                            if (F32MODE) {
-                                float vf = dn ? 0.0f : (float)v[c];
-                                const float gv = gf * vf;
-                                vf = rv[c] + gv;
-                                v[c] = (double)vf; ov[c] = vf;
-                            } else {
-                                double vd = dn ? 0.0 : v[c];
-                                const double gv = discount * vd;
-                                vd = (double)rv[c] + gv;
-                                v[c] = vd; ov[c] = (float)vd;
-                            }
-                        }
-                        if (col_ok) *reinterpret_cast<float4*>(out + t * N + n0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) sCarry[c * RT_COLS + lane] = v[c];
+        const int buf = (int)(p & 1);
+        const int64_t base = T - (int64_t)RW_ROWS * (p + 1);
+        if (p + 1 < npass) load_regs(p + 1);                   // next pass is in flight while this one is scanned
+        // ---- scan: latest row first, exact sequential recurrence, one column per lane
+#pragma unroll 8
+        for (int row = RW_ROWS - 1; row >= 0; --row) {
+            if (base + row < 0) break;
+            const float x = sR[buf][row][64 * w + lane];
+            const bool dn = sD[buf][row][64 * w + lane] != 0;
+            if (F32MODE) {
+                float vf = dn ? 0.0f : (float)v;
+                const float gv = gf * vf;
+                vf = x + gv;
+                v = (double)vf;
+                sR[buf][row][64 * w + lane] = vf;
+            } else {
+                double vd = dn ? 0.0 : v;
+                const double gv = discount * vd;
+                vd = (double)x + gv;
+                v = vd;
+                sR[buf][row][64 * w + lane] = (float)vd;
             }
-            __syncthreads();
         }
+        __syncthreads();
+        // ---- wide stores of the finished tile, then park the next pass in the other tile
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = w * RPW + i;
+            const int64_t t = base + row;
+            if (wide_ok && t >= 0) *reinterpret_cast<float4*>(out + t * N + cl) = *reinterpret_cast<const float4*>(&sR[buf][row][lane * 4]);
+        }
+        if (p + 1 < npass) park(buf ^ 1);
+        __syncthreads();
     }
+    (void)cs;
 }
 
 // Flat concatenated-episodes layout (the reference's own): each episode segment is scanned by
@@ -182,7 +207,7 @@ int32_t launch_returns_tn(const float* r, const uint8_t* done, float* out, int64
     if (T <= 0 || N <= 0) return PPO_OK;
     ProfScope ps("k_returns_tn");
     if (N % 4 == 0 && N >= 16384) {                  // wide columns: 1 KiB per wave row
-        dim3 gridw((unsigned)((N / 4 + RT_COLS - 1) / RT_COLS));
+        dim3 gridw((unsigned)((N + RW_COLS - 1) / RW_COLS));
         if (f32mode) hipLaunchKernelGGL(k_returns_tn_x4<1>, gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
         else hipLaunchKernelGGL(k_returns_tn_x4<0>, gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
         HIP_TRY(hipGetLastError());
