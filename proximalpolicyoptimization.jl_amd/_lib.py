@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_DIR, "libppo_hip.so")
+SO_PATH = os.environ.get("PPO_HIP_LIB") or os.path.join(_DIR, "libppo_hip.so")     # PPO_HIP_LIB: A/B builds
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)

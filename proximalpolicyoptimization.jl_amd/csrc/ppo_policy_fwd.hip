@@ -19,6 +19,25 @@
 #include "ppo_internal.h"
 #include "ppo_device.h"
 
+// activation stores of the train forward: tuning knobs for A/B builds (defaults are the shipped configuration)
+#ifndef PPO_FWD_STORE
+#define PPO_FWD_STORE 1          // 0: timing-only build without activation stores (results are wrong)
+#endif
+// Non-temporal stores for the 268 MB of saved activations: they are written once and read once by the backward
+// kernel much later, so they should not churn the L2; measured -4 % on the train forward (A/B in one process).
+#ifndef PPO_FWD_NT
+#define PPO_FWD_NT 1
+#endif
+#if PPO_FWD_NT
+static __device__ __forceinline__ void act_store_nt(float4* p, float4 v) {
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+#define ACT_STORE(ptr, val) act_store_nt((ptr), (val))
+#else
+#define ACT_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 struct FwdArgs {
     // inputs
     const int8_t* states;      // MODE 0/1: [B][H][F]; MODE 2: rollout states base (gathered by idx)
@@ -64,7 +83,10 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int S41 = F / 8;         // float4 groups of layer-1 k-steps
     constexpr int XB = F / 2;          // bytes of the state row held by one lane
     constexpr int XW = XB / 4;
-    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? 8 : 4;   // weight-fragment groups kept in flight per wave
+#ifndef PPO_FWD_PF
+#define PPO_FWD_PF 8
+#endif
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PPO_FWD_PF : 4;   // weight-fragment groups kept in flight per wave
     constexpr int A = 128 * TPS;
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     const int lane = threadIdx.x & 63;
@@ -144,11 +166,11 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
                     h1[o] = acc;
-                    if (MODE == 2) {
+                    if (MODE == 2 && PPO_FWD_STORE) {
                         float4* dst = a.act1 + ((size_t)tile * NT + o) * 4 * 64;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                            ACT_STORE(dst + q * 64 + lane, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
                     }
                 }
             }
@@ -187,11 +209,11 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
-                    if (MODE == 2) {
+                    if (MODE == 2 && PPO_FWD_STORE) {
                         float4* dst = a.act2 + ((size_t)tile * NT + o) * 4 * 64;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            dst[q * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                            ACT_STORE(dst + q * 64 + lane, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
                     }
                     const float4* w3 = a.w3p + (size_t)(half_o * NT + o) * 16;
 #pragma unroll
