@@ -41,9 +41,9 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     constexpr int LD = 33;                      // padded leading dimension (rows) of the LDS tiles
     constexpr int XDW = 32 * F / 4;             // dwords of one state
     constexpr int XPD = (XDW + NTHR - 1) / NTHR;  // state dwords staged per thread
-    constexpr int PF = (HID >= 256) ? 4 : 8;    // W2^T fragment groups in flight per wave (register budget)
+    constexpr int PF = (HID >= 256) ? 2 : 4;    // W2^T fragment groups per register set (two sets, ping-ponged)
     constexpr int S4 = HID / 8;                 // fragment groups of one W2^T tile
-    static_assert(S4 % PF == 0 && NTHR >= 256 && NTHR >= HID, "shape");
+    static_assert(S4 % (2 * PF) == 0 && NTHR >= 256 && NTHR >= HID, "shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sZ2 = smem;                          // [HID][33]  dZ2^T
     float* sH1 = sZ2 + HID * LD;                // [HID][33]  H1^T
@@ -176,10 +176,6 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        float4 ring[PF];                                          // W2^T stream (L2-resident)
-#pragma unroll
-        for (int g = 0; g < PF; ++g) ring[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
-
         // ================= phase B: small VALU grads, dH1 = W2^T dZ2 (MFMA), dZ1 -> LDS
         // small VALU grads, spread over all waves: lane (fl, hh) of wave w owns feature 32w+fl and rows
         // [16hh, 16hh+16); the two halves are added once at the end of the kernel.  The two waves that share
@@ -204,29 +200,49 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                 db3 += s;
             }
         };
+        // W2^T stream (L2-resident): two register sets of PF fragment groups, ping-ponged.  The loads of one set are
+        // issued BEFORE the MFMAs that consume the other (sched_barrier pins that order: left alone, hipcc sinks the
+        // loads below the MFMAs and waits vmcnt(0) right behind them, exposing an L2 round trip per 16 MFMAs).
+        float4 ringA[PF], ringB[PF];
+#pragma unroll
+        for (int g = 0; g < PF; ++g) ringA[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
         const bool grads_first = (2 * w < NT);                    // wave-uniform (w is an SGPR)
         const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;    // harmless re-load on the last tile
-        if (grads_first) { small_grads(); dma_next_act2(ntile); }
+        const int nidx = a.idx[ntile / a.tps];                    // next tile's transition id, consumed in phase D
+        if (grads_first) small_grads();
         {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
-            const char* wn = w2t + (size_t)PF * 1024;                  // scalar pointer, advances per iteration
-#pragma unroll 1
-            for (int s0 = 0; s0 < S4; s0 += PF, bz += 8 * PF * LD, wn += (size_t)PF * 1024) {
+            const char* wn = w2t + (size_t)PF * 1024;                // scalar pointer to the next group set
+            auto mfma_set = [&](const float4 (&rg)[PF]) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
-                    const float4 ww = ring[u];
-                    ring[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));   // tail padding covers the over-read
                     float b[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.x, b[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.y, b[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.z, b[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w, b[3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
                 }
+                bz += 8 * PF * LD;
+            };
+#pragma unroll 1
+            for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringB[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));
+                wn += (size_t)PF * 1024;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringA[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));   // tail padding covers the over-read
+                wn += (size_t)PF * 1024;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringB);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -239,10 +255,12 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         STAMP(2);
         __syncthreads();
         STAMP(3);
-        if (!grads_first) dma_next_act2(ntile);                   // after the barrier: __syncthreads drains vmcnt
+        // LDS-DMA of the next tile's layer-2 fragments into this wave's (now idle) sH2 slice.  Issued here, after
+        // the barrier, by every wave: while a DMA is pending hipcc turns every counted vmcnt(N) into vmcnt(0), which
+        // must not happen inside the weight-stream loop of phase B; phases C/D have no counted waits.
+        dma_next_act2(ntile);
 
         // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
-        const int nidx = a.idx[ntile / a.tps];                    // next tile's transition id, consumed in phase D
         {
             const float* g1 = sZ1 + (32 * w + j) * LD + 16 * h;
             float s1 = 0.f;
