@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #ifndef PPO_FWD_PF
 #define PPO_FWD_PF 8
 #endif
+#ifndef PPO_FWD_OUNROLL
+#define PPO_FWD_OUNROLL 1
+#endif
     constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PPO_FWD_PF : 4;   // weight-fragment groups kept in flight per wave
     constexpr int A = 128 * TPS;
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                 float4 ring[PF];
 #pragma unroll
                 for (int g = 0; g < PF; ++g) ring[g] = wp[(size_t)g * 64];
-#pragma unroll 1
+#pragma unroll PPO_FWD_OUNROLL
                 for (int o = 0; o < NT; ++o) {
                     f32x16 acc;
 #pragma unroll
