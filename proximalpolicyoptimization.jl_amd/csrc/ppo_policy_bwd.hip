@@ -37,7 +37,10 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     constexpr int NT = HID / 32;                // feature tiles == waves per workgroup (wave w owns tile w)
     constexpr int NTHR = NT * 64;
     constexpr int FP = ((F + 31) / 32) * 32;
-    constexpr int NI = FP / 32;
+    constexpr int NI = FP / 32;                 // i-tiles in the slab layout (last one partly padding)
+    constexpr int NIM = F / 32;                 // full 32-column i-tiles done on the MFMA pipe
+    constexpr int FT = F % 32;                  // tail columns (8 for F=72, 24 for F=216): VALU beside the MFMAs
+    static_assert(FT % 4 == 0, "F must be a multiple of 4");
     constexpr int LD = 33;                      // padded leading dimension (rows) of the LDS tiles
     constexpr int XDW = 32 * F / 4;             // dwords of one state
     constexpr int XPD = (XDW + NTHR - 1) / NTHR;  // state dwords staged per thread
@@ -49,8 +52,9 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     float* sH1 = sZ2 + HID * LD;                // [HID][33]  H1^T
     float* sH2 = sH1 + HID * LD;                // [HID][33]  H2^T
     float* sZ1 = sH2 + HID * LD;                // [HID][33]  dZ1^T
-    float* sX = sZ1 + HID * LD;                 // [FP][33]   X^T (float)
-    float* sDY = sX + FP * LD;                  // [32][4]
+    float* sX = sZ1 + HID * LD;                 // [NIM*32][33]  X^T (float), MFMA part
+    float* sXt = sX + NIM * 32 * LD;            // [32][FT]      X tail columns, row-major per tile row
+    float* sDY = sXt + 32 * (FT > 0 ? FT : 4);  // [32][4]
     float* sW3 = sDY + 32 * 4;                  // [HID][4]   W3[:,f] per feature (staged once)
 
     const int tid = threadIdx.x;
@@ -61,18 +65,20 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     const int j = lane & 31, h = lane >> 5;
 
     f32x16 accW2[NT];
-    f32x16 accW1[NI];
+    f32x16 accW1[NIM];
+    float tl[FT > 0 ? FT : 1];                  // dW1[k = 32w+j][NIM*32 + c], rows of this lane half
+#pragma unroll
+    for (int c = 0; c < (FT > 0 ? FT : 1); ++c) tl[c] = 0.0f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW2[kt][r] = 0.0f;
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
+    for (int it = 0; it < NIM; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW1[it][r] = 0.0f;
     float db1 = 0.f, db2 = 0.f, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int i = tid; i < FP * LD; i += NTHR) sX[i] = 0.0f;     // rows i >= F stay zero (padding of dW1)
     if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
         const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
@@ -86,13 +92,24 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     // slice: rows [32w, 32w+32) of sH2 are written (phase A) and read (small_grads) by wave w only, so once the
     // wave's small_grads are done the slice is free until phase A of the next tile.  No registers involved.
     float* const h2slice = sH2 + (size_t)(32 * w) * LD;
+    // The DMA is issued from inline asm on purpose: if hipcc knows an LDS-DMA is pending it (a) puts vmcnt(0) in front
+    // of the next LDS read of ANY address (here: the VALU gradient loops, i.e. a full HBM round trip of stall),
+    // (b) degrades every counted vmcnt(N) to vmcnt(0) and (c) drains it at each __syncthreads().  The only consumer
+    // is this same wave in phase A of the next tile, behind an explicit s_waitcnt vmcnt(0).  M0 (the LDS-DMA
+    // destination base) is saved/restored inside the statement (cdna_hip_programming.md 5.7).
+    const unsigned h2slice_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)h2slice);
     auto dma_next_act2 = [&](int64_t t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of the slice have returned
         const float4* src = a.act2 + ((size_t)t * NT + w) * 4 * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 64),
-                                             (__attribute__((address_space(3))) void*)(h2slice + q * 256), 16, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            unsigned keep;
+            const float4* gsrc = src + q * 64;
+            const unsigned dst = h2slice_lds + (unsigned)q * 1024u;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
     };
     if ((int64_t)blockIdx.x < a.B) dma_next_act2(blockIdx.x);
 
@@ -114,7 +131,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     if ((int64_t)blockIdx.x < a.B)
         issue_tile_loads(blockIdx.x, __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
 #ifdef PPO_BWD_STAMP
-    unsigned long long st_sum[7] = {0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #define STAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
 #else
 #define STAMP(i) do {} while (0)
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                 constexpr int dummy = 0; (void)dummy;
                 const int fo = e + 8 * q;                          // feature offset inside the tile
                 const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
-                const float dh = ww.x * dy.x + ww.y * dy.y + ww.z * dy.z + ww.w * dy.w;
+                const float dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
                 z2b[fo * LD] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
                 h2b[fo * LD] = h2v[e];
                 h1b[fo * LD] = h1v[e];
@@ -170,7 +187,11 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             if (d < XDW) {
                 const int row = d / (F / 4), c = d % (F / 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sX[(4 * c + e) * LD + row] = (float)(int)(int8_t)(xd[i] >> (8 * e));
+                for (int e = 0; e < 4; ++e) {
+                    const float xv = (float)(int)(int8_t)(xd[i] >> (8 * e));
+                    if (4 * c < NIM * 32) sX[(4 * c + e) * LD + row] = xv;
+                    else sXt[row * FT + (4 * c - NIM * 32) + e] = xv;
+                }
             }
         }
         STAMP(0);
@@ -186,12 +207,21 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
             const float* gy = sDY + 64 * h;
             float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const float z = gz[r];
-                const float hv = gh[r];
-                const float4 y = *reinterpret_cast<const float4*>(gy + r * 4);
-                s2 += z; d0 += y.x * hv; d1 += y.y * hv; d2 += y.z * hv; d3 += y.w * hv;
+#pragma unroll 1
+            for (int rc = 0; rc < 16; rc += 4) {                   // reads of 4 rows first, then the arithmetic
+                float z[4], hv[4];
+                float4 y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    z[i] = gz[rc + i]; hv[i] = gh[rc + i];
+                    y[i] = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s2 += z[i]; d0 = fmaf(y[i].x, hv[i], d0); d1 = fmaf(y[i].y, hv[i], d1); d2 = fmaf(y[i].z, hv[i], d2); d3 = fmaf(y[i].w, hv[i], d3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             db2 += s2; dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
             if (tid < 4) {
@@ -208,7 +238,6 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         for (int g = 0; g < PF; ++g) ringA[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
         const bool grads_first = (2 * w < NT);                    // wave-uniform (w is an SGPR)
         const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;    // harmless re-load on the last tile
-        const int nidx = a.idx[ntile / a.tps];                    // next tile's transition id, consumed in phase D
         if (grads_first) small_grads();
         {
             f32x16 acc;
@@ -261,13 +290,39 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         dma_next_act2(ntile);
 
         // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
-        {
+        // db1 and the dW1 tail columns (i >= NIM*32) on the VALU: lane (j, h) owns k = 32w+j and tile rows
+        // [16h, 16h+16).  Like small_grads, the two waves of a SIMD run this at opposite ends of the C/D phases.
+        auto tail_grads = [&]() {
             const float* g1 = sZ1 + (32 * w + j) * LD + 16 * h;
+            const float* xt = sXt + 16 * h * FT;
             float s1 = 0.f;
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) s1 += g1[r];
+            // the LDS reads of 4 rows are issued together, then consumed (left alone hipcc emits
+            // read / lgkmcnt(0) / use for every single read: ~40 serialized LDS round trips per tile)
+#pragma unroll 1
+            for (int rc = 0; rc < 16; rc += 4) {
+                float z[4];
+                float4 xv[4][FT / 4 > 0 ? FT / 4 : 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    z[i] = g1[rc + i];
+#pragma unroll
+                    for (int c4 = 0; c4 < FT / 4; ++c4) xv[i][c4] = *reinterpret_cast<const float4*>(xt + (rc + i) * FT + 4 * c4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1 += z[i];
+#pragma unroll
+                    for (int c4 = 0; c4 < FT / 4; ++c4) {
+                        tl[4 * c4 + 0] = fmaf(z[i], xv[i][c4].x, tl[4 * c4 + 0]); tl[4 * c4 + 1] = fmaf(z[i], xv[i][c4].y, tl[4 * c4 + 1]);
+                        tl[4 * c4 + 2] = fmaf(z[i], xv[i][c4].z, tl[4 * c4 + 2]); tl[4 * c4 + 3] = fmaf(z[i], xv[i][c4].w, tl[4 * c4 + 3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             db1 += s1;
-        }
+        };
+        if (grads_first) tail_grads();
         {
             const float* pa = sZ2 + (32 * w + j) * LD + h;
             const float* pb = sH1 + j * LD + h;
@@ -282,32 +337,43 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                     accW2[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kt], accW2[kt], 0, 0, 0);
             }
         }
+        STAMP(7);
         // ================= phase D: dW1[k,i] += sum_rows dZ1[k,row] * X[i,row]     (wave w: k-tile w)
         // register pressure is lowest here: the NEXT tile's layer-1 fragments, dY and state dwords are issued
         // now (22 registers) and land under this phase's MFMAs and the barrier; consumed in phase A.
         // Unconditional (a harmless re-load on the last tile): no phi, so the staging registers live D..A only.
-        issue_tile_loads(ntile, __builtin_amdgcn_readfirstlane(nidx));
+        {
+            // next tile's transition id through the scalar cache (s_load + lgkmcnt): a vector load here would be
+            // waited for with vmcnt(0), which also drains the pending LDS-DMA (a full HBM round trip)
+            const int32_t* ip = a.idx + ntile / a.tps;
+            int nidx;
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nidx) : "s"(ip) : "memory");
+            issue_tile_loads(ntile, nidx);
+        }
+        STAMP(8);
         {
             const float* pa = sZ1 + (32 * w + j) * LD + h;
             const float* pb = sX + j * LD + h;
 #pragma unroll 4
             for (int s = 0; s < 16; ++s) {
                 const float av = pa[2 * s];
-                float bv[NI];
+                float bv[NIM];
 #pragma unroll
-                for (int it = 0; it < NI; ++it) bv[it] = pb[32 * it * LD + 2 * s];
+                for (int it = 0; it < NIM; ++it) bv[it] = pb[32 * it * LD + 2 * s];
 #pragma unroll
-                for (int it = 0; it < NI; ++it)
+                for (int it = 0; it < NIM; ++it)
                     accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[it], accW1[it], 0, 0, 0);
             }
         }
+        STAMP(9);
+        if (!grads_first) tail_grads();
         STAMP(4);
         __syncthreads();
         STAMP(5);
     }
 #ifdef PPO_BWD_STAMP
     if (a.stamps && lane == 0 && (w == 0 || w == NT - 1))
-        for (int i = 0; i < 7; ++i) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 7 + i] = st_sum[i];
+        for (int i = 0; i < 10; ++i) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 10 + i] = st_sum[i];
 #endif
 
     // ================= write the slab (fragment order; k_grad_reduce maps it to Flux order)
@@ -323,9 +389,18 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW2[((size_t)(w * NT + kt) * 16 + r) * 64 + lane] = accW2[kt][r];
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
+    for (int it = 0; it < NIM; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = accW1[it][r];
+    if (FT > 0) {   // tail columns: combine the two row halves, then place them at their fragment-order positions of i-tile NIM
+#pragma unroll
+        for (int c = 0; c < FT; ++c) tl[c] += __shfl_xor(tl[c], 32);
+        if (h == 0) {
+            const int r = (j & 3) + 4 * (j >> 3), hh = (j >> 2) & 1;      // accumulator register / lane half that holds row k = 32w+j
+#pragma unroll
+            for (int c = 0; c < FT; ++c) sW1[((size_t)(w * NI + NIM) * 16 + r) * 64 + c + 32 * hh] = tl[c];
+        }
+    }
     {   // combine the two row halves (lanes l and l^32 own the same feature)
         db1 += __shfl_xor(db1, 32); db2 += __shfl_xor(db2, 32);
 #pragma unroll
@@ -344,14 +419,14 @@ unsigned long long* g_bwd_stamps = nullptr;
 extern "C" int32_t ppo_debug_bwd_stamps(unsigned long long* out) {
     if (!g_bwd_stamps) return -1;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out, g_bwd_stamps, 256 * 14 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+    return hipMemcpy(out, g_bwd_stamps, 256 * 20 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 #endif
 
 template <int F, int HID>
 static size_t bwd_lds_bytes() {
-    constexpr int FP = ((F + 31) / 32) * 32;
-    return sizeof(float) * ((size_t)4 * HID * 33 + (size_t)FP * 33 + 32 * 4 + (size_t)HID * 4);
+    return sizeof(float) * ((size_t)4 * HID * 33 + (size_t)(F / 32) * 32 * 33 + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
+                            (size_t)HID * 4);
 }
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
@@ -363,7 +438,7 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
     a.stamps = nullptr;
 #ifdef PPO_BWD_STAMP
-    { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 14 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
+    { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 20 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
 #endif
     const int nwg = (int)(a.B < 256 ? a.B : 256);
     p->nwg_bwd = nwg;

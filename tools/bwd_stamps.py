@@ -17,11 +17,11 @@ ds = PPO.construct_dataset(ro)
 sel = np.arange(1, 4097)
 for _ in range(3):
     PPO.forward_backward(pol, ds, sel, 0.05, 0.01)
-out = np.zeros(256 * 14, np.uint64)
+out = np.zeros(256 * 20, np.uint64)
 L.ppo_debug_bwd_stamps.argtypes = [C.c_void_p]
 assert L.ppo_debug_bwd_stamps(out.ctypes.data) == 0
-s = out.reshape(256, 2, 7).astype(np.float64)
-names = ["A transform+LDS", "barrier1", "B dX", "barrier2", "C+D dW", "barrier3", "A global loads"]
+s = out.reshape(256, 2, 10).astype(np.float64)
+names = ["A transform+LDS", "barrier1", "B dX", "barrier2", "D2 late tail", "barrier3", "A wait loads", "C dW2 (+tail)", "D0 issue next loads", "D1 dW1 mfma loop"]
 for wv in (0, 1):
     m = s[:, wv, :].mean(axis=0)
     print("wave %s: total %.0f cycles/WG (%.0f per tile)" % ("0" if wv == 0 else "last", m.sum(), m.sum() / 16))
