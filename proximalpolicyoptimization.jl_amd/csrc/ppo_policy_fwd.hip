@@ -44,6 +44,8 @@ struct FwdArgs {
     const uint32_t* active;    // same indexing as states
     const int32_t* idx;        // MODE 2: transition id per tile
     int64_t B;
+    unsigned long long* stamps;   // diagnostic build only (-DPPO_FWD_STAMP)
+    int wg_sync;               // 1: every wave of a workgroup runs the same number of tiles -> per-chunk barriers allowed
     const float4* w1p; const float4* w2p; const float4* b1p; const float4* b2p; const float4* w3p; const float* b3;
     // MODE 0
     float* probs_out;
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #ifndef PPO_FWD_PF
 #define PPO_FWD_PF 8
 #endif
+#ifndef PPO_FWD_WGSYNC
+#define PPO_FWD_WGSYNC 0
+#endif
 #ifndef PPO_FWD_OUNROLL
 #define PPO_FWD_OUNROLL 1
 #endif
@@ -97,6 +102,15 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     const int h = lane >> 5;           // lane half = k parity of the MFMA step
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+
+    // W3 fragments and the two bias packs are read once per output tile by every wave: staged in LDS once per
+    // workgroup so the per-tile epilogues see an LDS round trip instead of a global (L1/L2) one
+    __shared__ __attribute__((aligned(16))) float4 sW3[2 * NT * 16];     // [half][tile][reg]  (HID*4 floats)
+    __shared__ __attribute__((aligned(16))) float4 sB1[NT * 2 * 4];      // [tile][half][4]    (HID floats)
+    __shared__ __attribute__((aligned(16))) float4 sB2[NT * 2 * 4];
+    for (int i = threadIdx.x; i < 2 * NT * 16; i += 256) sW3[i] = a.w3p[i];
+    for (int i = threadIdx.x; i < NT * 8; i += 256) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    __syncthreads();
 
     // the rows of the NEXT 32-row tile are fetched while the current one computes (the gather through idx is two
     // dependent HBM round trips that one wave per SIMD cannot hide otherwise)
@@ -111,6 +125,12 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     };
     if (PFX && wave < a.B) fetch_rows(wave, 0);
 
+#ifdef PPO_FWD_STAMP
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t = clock64();
+#define FSTAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
     for (int64_t state = wave; state < a.B; state += nwaves) {
         const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
         const uint32_t act = a.active[sid];
@@ -139,6 +159,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                 else fetch_rows(state + nwaves < a.B ? state + nwaves : state, 0);
             }
 
+            FSTAMP(0);
             // ---- layer 1: H1^T[o-tile] = W1[o-tile,:] * X^T  (accumulator initialised with the bias)
             // The weight stream of a layer is one linear run of 1 KiB fragment groups (4 MFMA k-steps each);
             // a PF-deep register ring keeps PF groups in flight so the single wave of a SIMD never waits on L2.
@@ -153,7 +174,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 b = a.b1p[(o * 2 + half_o) * 4 + q];
+                        const float4 b = sB1[(o * 2 + half_o) * 4 + q];
                         acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                     }
 #pragma unroll
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                 }
             }
 
+            FSTAMP(1);
             // ---- layer 2 (MFMA, B operands = layer-1 accumulators) + layer 3 (VALU dot epilogue)
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
             {
@@ -189,10 +211,13 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                 for (int g = 0; g < PF; ++g) ring[g] = wp[(size_t)g * 64];
 #pragma unroll PPO_FWD_OUNROLL
                 for (int o = 0; o < NT; ++o) {
+                    // keep the 4 waves of the workgroup on the same 32 KiB weight chunk: their 1 KiB fragment loads then
+                    // hit in the CU's L1 for three of the four waves (speed only; skipped when trip counts differ)
+                    if (PPO_FWD_WGSYNC && a.wg_sync) __builtin_amdgcn_s_barrier();
                     f32x16 acc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 b = a.b2p[(o * 2 + half_o) * 4 + q];
+                        const float4 b = sB2[(o * 2 + half_o) * 4 + q];
                         acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                     }
                     const float4* wo = wp + (size_t)o * S42 * 64;
@@ -210,6 +235,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[t][4 * r4 + 3], acc, 0, 0, 0);
                         }
                     }
+                    FSTAMP(2);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
                     if (MODE == 2 && PPO_FWD_STORE) {
@@ -218,13 +244,14 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                         for (int q = 0; q < 4; ++q)
                             ACT_STORE(dst + q * 64 + lane, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
                     }
-                    const float4* w3 = a.w3p + (size_t)(half_o * NT + o) * 16;
+                    const float4* w3 = sW3 + (half_o * NT + o) * 16;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float4 w = w3[r];
                         p0 = fmaf(w.x, acc[r], p0); p1 = fmaf(w.y, acc[r], p1);
                         p2 = fmaf(w.z, acc[r], p2); p3 = fmaf(w.w, acc[r], p3);
                     }
+                    FSTAMP(3);
                 }
             }
             const float l0 = (p0 + __shfl_xor(p0, 32)) + a.b3[0];
@@ -242,6 +269,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             }
         }
 
+        FSTAMP(4);
         // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
         bool on[TPS];
         float m = -INFINITY;
@@ -346,7 +374,12 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             }
             if (lane == 0) { a.loss_terms[state * 2] = minval; a.loss_terms[state * 2 + 1] = (double)(-hl); }
         }
+        FSTAMP(5);
     }
+#ifdef PPO_FWD_STAMP
+    if (a.stamps && lane == 0 && wave < 1024)
+        for (int i = 0; i < 6; ++i) a.stamps[wave * 6 + i] = st_sum[i];
+#endif
 }
 
 // rand(Categorical) on given probabilities (parity entry point, src/collect_rollouts.jl:6-7):
@@ -373,6 +406,7 @@ static int32_t dispatch_fwd(ppo_policy_s* p, const FwdArgs& args, int64_t B, int
     do {                                                                                                 \
         const int64_t cap = 256 * FwdCfg<FF, HH>::WPS;                                                   \
         const unsigned grid = (unsigned)(need < cap ? need : cap);                                       \
+        const_cast<FwdArgs&>(args).wg_sync = (B % ((int64_t)grid * 4) == 0) ? 1 : 0;                     \
         hipLaunchKernelGGL((k_policy_fwd<FF, HH, MODE, TT>), dim3(grid), dim3(256), 0, ppo_stream(), args); \
     } while (0)
     if (p->F == 72 && p->HID == 256 && tps == 1) LAUNCH(72, 256, 1);
@@ -386,7 +420,21 @@ static int32_t dispatch_fwd(ppo_policy_s* p, const FwdArgs& args, int64_t B, int
     return PPO_OK;
 }
 
+#ifdef PPO_FWD_STAMP
+static unsigned long long* g_fwd_stamps = nullptr;
+extern "C" int32_t ppo_debug_fwd_stamps(unsigned long long* out) {
+    if (!g_fwd_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_fwd_stamps, 1024 * 6 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 static void fill_weights(ppo_policy_s* p, FwdArgs& a) {
+    a.stamps = nullptr;
+#ifdef PPO_FWD_STAMP
+    if (!g_fwd_stamps) (void)hipMalloc((void**)&g_fwd_stamps, 1024 * 6 * 8);
+    a.stamps = g_fwd_stamps;
+#endif
     a.w1p = (const float4*)p->w1p.p; a.w2p = (const float4*)p->w2p.p; a.b1p = (const float4*)p->b1p.p;
     a.b2p = (const float4*)p->b2p.p; a.w3p = (const float4*)p->w3p.p; a.b3 = p->b3.p;
 }
