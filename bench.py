@@ -26,6 +26,7 @@ import numpy as np  # noqa: E402
 N_ENVS, T_STEPS, HID, F, EPOCHS, MINIBATCH = 4096, 128, 256, 72, 4, 4096
 GAMMA, EPS, ENT_W, LR = 1.0, 0.05, 0.01, 1e-4
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--dtype bf16 runs only)
 
 
 def flops_per_state(kind):
@@ -69,7 +70,7 @@ def cpu_baseline():
 
 
 def main():
-    global T_STEPS, EPOCHS
+    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -77,9 +78,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--t-steps", type=int, default=T_STEPS, help="profiling only: shorter rollout (flagged in the output)")
     ap.add_argument("--epochs", type=int, default=EPOCHS, help="profiling only: fewer epochs (flagged in the output)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (the headline line); bf16 = the config-5 arithmetic on the same workload "
+                         "(flagged in the output, not the headline)")
+    ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default 4096 = the headline workload)")
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS)
+    N_ENVS = MINIBATCH = args.envs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,7 +116,7 @@ def main():
 
     dp = PPO.DataParallel(rank, world, force_hook=use_dist)
     env = PPO.HipVecEnv(num_envs=N_ENVS, Q=8, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
-    pol = PPO.HipPolicy(F, HID, 2, 4, seed=0)
+    pol = PPO.HipPolicy(F, HID, 2, 4, seed=0, dtype=args.dtype)
     opt = PPO.Optimiser(PPO.Adam(LR))
     ro = PPO.BufferRollouts()
 
@@ -140,6 +147,7 @@ def main():
 
     # ---- roofline leg: per-kernel HIP-event durations of one more iteration (outside the timed region)
     roof, kernels = None, {}
+    peak = PEAK_FP32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     if rank == 0:
         PPO.profile_enable(True)
         iteration(args.warmup + args.steps)
@@ -151,8 +159,8 @@ def main():
                 avg = ms / n
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
-                                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
-        for name in ("k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam"):
+                                 "frac": round(tf / peak, 4)}
+        for name in ("k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam"):
             ms, n = PPO.profile_get(name)
             if n:
                 kernels[name] = {"avg_ms": round(ms / n, 4), "launches": n}
@@ -168,12 +176,14 @@ def main():
             # inside this process); null when the file is absent
             traffic, tsrc = None, None
             try:
+                if args.dtype != "f32":
+                    raise KeyError("PMC traffic is recorded for the fp32 kernels only")
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
                 traffic = pm["kernels"]["k_policy_bwd<72, 256>"]["hbm_bytes"]
                 tsrc = "profiles/r01_pmc_traffic.json (" + pm["source"] + ")"
             except Exception:
                 pass
-            roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+            roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
                     "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
@@ -189,13 +199,15 @@ def main():
             "metric": "env-steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "4096 parallel synthetic rand-poly-shaped envs per GPU (Q=8,H=32,A=128,F=72 int8), "
-                                   "2x256 MLP policy fp32, T=128 steps/iteration, 4 epochs, minibatch 4096/GPU, "
-                                   "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)",
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=8,H=32,A=128,F=72 int8), "
+                                   "2x256 MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
+                                   "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)"
+                                   % (N_ENVS, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
+                                      T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world},
-            "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced,
+            "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced, "headline_config": not nonheadline,
             "target_frac_of_1e6": value / 1e6,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -100,6 +100,14 @@ int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null);
 /* SimplePolicy.Policy(in, hidden, num_hidden_layers, out)  test/policy.jl:9-19 */
 int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers,
                           int32_t out_per_edge, ppo_policy_t* out);
+/* arithmetic type of the policy MLP (BASELINE config 5: "bf16 MLP on MFMA + fp32 GAE").  PPO_DTYPE_F32 (default):
+ * exact fp32 MFMA.  PPO_DTYPE_BF16: weights and layer inputs rounded to bfloat16 (RNE), fp32 accumulation, bias,
+ * leakyrelu, softmax, sampling, loss and Adam (fp32 master parameters) unchanged; saved activations and the
+ * gradient signals dZ are bf16.  Call before training; the reference has no counterpart (Flux Float32 only). */
+#define PPO_DTYPE_F32 0
+#define PPO_DTYPE_BF16 1
+int32_t ppo_policy_set_dtype(ppo_policy_t pol, int32_t dtype);
+int32_t ppo_policy_get_dtype(ppo_policy_t pol, int32_t* dtype);
 int32_t ppo_policy_destroy(ppo_policy_t pol);
 int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n);
 int32_t ppo_policy_set_params(ppo_policy_t pol, const float* flat);     /* Flux.params order */

@@ -145,3 +145,82 @@ def adam_step(params, grad, m, v, beta_pow, eta=1e-4, beta1=0.9, beta2=0.999, ep
     delta = (m2.astype(np.float64) / (1 - beta_pow[0]) /
              (np.sqrt(v2.astype(np.float64) / (1 - beta_pow[1])) + eps) * eta).astype(np.float32)
     return (params - delta).astype(np.float32), m2, v2, np.array([beta_pow[0] * beta1, beta_pow[1] * beta2])
+
+
+# ---------------------------------------------------------------- bf16 compute mode (ppo_policy_set_dtype(PPO_DTYPE_BF16))
+# The reference is Float32 only; this restates the build's bf16 mode (csrc/ppo_policy_bf16.hip): weights and layer
+# inputs rounded to bfloat16 (round-to-nearest-even), exact products, accumulation here in float64 (the device
+# accumulates in fp32 in MFMA order -> compare with a tolerance), bias/leakyrelu/softmax/loss in higher precision,
+# backward signals dY, dZ2, dZ1 rounded to bf16 before they enter a product.  PARITY UNPINNED against the reference.
+def bf16_round(x):
+    """float -> nearest bfloat16 value (RNE), returned as float64 array."""
+    a = np.ascontiguousarray(np.asarray(x, np.float32))
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    out = (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32).astype(np.float64)
+    return out.reshape(a.shape)
+
+
+def _lrelu(z):
+    return np.where(z > 0, z, 0.01 * z)
+
+
+def mlp_forward_bf16(params, F, HID, x):
+    """x: [B,H,F] ints.  Returns (logits [B, H*4] float64, h1b, h2b) with the bf16 rounding points of the device."""
+    (W1, b1), (W2, b2), (W3, b3) = unpack_params(params, F, HID, 2)
+    W1b, W2b, W3b = bf16_round(W1), bf16_round(W2), bf16_round(W3)
+    X = np.asarray(x, np.float64)                                        # int8 values: exact in bf16
+    h1 = _lrelu(np.float32(X @ W1b.T + b1.astype(np.float64)))           # fp32 accumulator, fp32 leakyrelu
+    h1b = bf16_round(h1)
+    h2 = _lrelu(np.float32(h1b @ W2b.T + b2.astype(np.float64)))
+    h2b = bf16_round(h2)
+    y = h2b @ W3b.T + b3.astype(np.float64)                              # [B,H,4]
+    return y.reshape(y.shape[0], -1), h1b, h2b
+
+
+def action_probabilities_bf16(params, F, HID, x, masks):
+    logits, _, _ = mlp_forward_bf16(params, F, HID, x)
+    l = logits + np.asarray(masks, np.float64)
+    l = l - l.max(axis=1, keepdims=True)
+    e = np.exp(l)
+    return e / e.sum(axis=1, keepdims=True)
+
+
+def step_batch_grad_bf16(params, F, HID, states, masks, actions0, p_old, adv, eps, entropy_weight):
+    """Gradient of the step_batch! loss (src/train.jl:35-46,54-84) in the bf16 compute mode.
+    Returns (flat grad in Flux order, ppoloss, entropy_weight*entropyloss)."""
+    (W1, b1), (W2, b2), (W3, b3) = unpack_params(params, F, HID, 2)
+    W2b, W3b = bf16_round(W2), bf16_round(W3)
+    X = np.asarray(states, np.float64)
+    B, H, _ = X.shape
+    A = H * 4
+    logits, h1b, h2b = mlp_forward_bf16(params, F, HID, X)
+    l = logits + np.asarray(masks, np.float64)
+    l = l - l.max(axis=1, keepdims=True)
+    e = np.exp(l)
+    p = e / e.sum(axis=1, keepdims=True)
+    a0 = np.asarray(actions0, np.int64)
+    advd, pod = np.asarray(adv, np.float64), np.asarray(p_old, np.float64)
+    psel = p[np.arange(B), a0]
+    gain = psel / pod * advd
+    clip = np.where(advd >= 0, (1.0 + eps) * advd, (1.0 - eps) * advd)
+    unclipped = gain < clip
+    ppoloss = -np.mean(np.where(unclipped, gain, clip))
+    sA = float(np.float32(1e-8)) / A
+    sp = p + sA
+    lg = np.log(sp)
+    entloss = entropy_weight * np.mean((sp * lg).sum(axis=1))            # entropy_weight * (-H)
+    dp = (entropy_weight / B) * (lg + 1.0)
+    dp[np.arange(B), a0] += np.where(unclipped, -(advd / pod) / B, 0.0)
+    dl = p * (dp - (p * dp).sum(axis=1, keepdims=True))                  # [B,A]
+    dY = bf16_round(dl).reshape(B, H, 4)                                 # device: rounded once in the forward kernel
+    dW3 = np.einsum("bho,bhf->of", dY, h2b)
+    db3 = dY.sum(axis=(0, 1))
+    dZ2 = bf16_round(np.float32((dY @ W3b) * np.where(h2b > 0, 1.0, 0.01)))
+    dW2 = np.einsum("bhf,bhk->fk", dZ2, h1b)
+    db2 = dZ2.sum(axis=(0, 1))
+    dZ1 = bf16_round(np.float32((dZ2 @ W2b) * np.where(h1b > 0, 1.0, 0.01)))
+    dW1 = np.einsum("bhk,bhi->ki", dZ1, X)
+    db1 = dZ1.sum(axis=(0, 1))
+    g = np.concatenate([dW1.ravel(order="F"), db1, dW2.ravel(order="F"), db2, dW3.ravel(order="F"), db3])
+    return g, float(ppoloss), float(entloss)

@@ -232,11 +232,20 @@ class HipPolicy:
     """SimplePolicy.Policy(in_channels, hidden_channels, num_hidden_layers, num_output) (test/policy.jl:9-19)
     with parameters resident on the GPU.  `params` is the flat Flux.params vector (W [out,in] column-major)."""
 
-    def __init__(self, in_channels, hidden_channels, num_hidden_layers, num_output, seed=0):
+    DTYPES = {"f32": 0, "bf16": 1}
+
+    def __init__(self, in_channels, hidden_channels, num_hidden_layers, num_output, seed=0, dtype="f32"):
+        """dtype: arithmetic of the MLP's three Dense products -- "f32" (exact fp32 MFMA, the reference's Float32)
+        or "bf16" (bf16 MFMA with fp32 accumulation, BASELINE config 5; ppo_policy_set_dtype)."""
+        if dtype not in self.DTYPES:
+            raise PPOError(-1, "AssertionError: dtype must be 'f32' or 'bf16'")
         h = C.c_void_p()
         call("ppo_policy_create", int(in_channels), int(hidden_channels), int(num_hidden_layers), int(num_output),
              C.byref(h))
         self._h = h
+        self.dtype = dtype
+        if dtype != "f32":
+            call("ppo_policy_set_dtype", h, self.DTYPES[dtype])
         self.in_channels, self.hidden_channels = in_channels, hidden_channels
         self.num_hidden_layers, self.num_output = num_hidden_layers, num_output
         n = C.c_int64(0)

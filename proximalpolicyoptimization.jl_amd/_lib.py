@@ -47,6 +47,8 @@ SIGNATURES = {
     "ppo_env_get_internal": [H, c_i8p, c_i8p, c_i32p, c_u32p, c_u32p],
     "ppo_env_check_errors": [H, c_i32p],
     "ppo_policy_create": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, HP],
+    "ppo_policy_set_dtype": [H, C.c_int32],
+    "ppo_policy_get_dtype": [H, C.POINTER(C.c_int32)],
     "ppo_policy_destroy": [H],
     "ppo_policy_num_params": [H, c_i64p],
     "ppo_policy_set_params": [H, c_f32p],

@@ -339,6 +339,20 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers, 
     return PPO_OK;
 }
 
+int32_t ppo_policy_set_dtype(ppo_policy_t pol, int32_t dtype) {
+    ARG_CHECK(pol, "policy_set_dtype: null policy");
+    ARG_CHECK(dtype == PPO_DTYPE_F32 || dtype == PPO_DTYPE_BF16, "policy_set_dtype: dtype must be PPO_DTYPE_F32 or PPO_DTYPE_BF16");
+    if (dtype == PPO_DTYPE_BF16 && !pol->w1b.p) {
+        const size_t HID = pol->HID, KS1 = bf16_ks1(pol->F);
+        PPO_TRY(pol->w1b.alloc(HID * KS1 * 16)); PPO_TRY(pol->w2b.alloc(HID * HID)); PPO_TRY(pol->w2tb.alloc(HID * HID));
+        PPO_TRY(pol->w3c.alloc(HID * PPO_OUT)); PPO_TRY(pol->w3tb.alloc(HID * PPO_OUT));
+        HIP_TRY(hipMemsetAsync(pol->w1b.p, 0, pol->w1b.n * 2, g_stream));      // k-slots >= F stay zero
+    }
+    pol->dtype = dtype;
+    return launch_pack_params(pol);
+}
+int32_t ppo_policy_get_dtype(ppo_policy_t pol, int32_t* dtype) { ARG_CHECK(pol && dtype, "null"); *dtype = pol->dtype; return PPO_OK; }
+
 int32_t ppo_policy_destroy(ppo_policy_t pol) { if (pol) { (void)hipStreamSynchronize(g_stream); delete pol; } return PPO_OK; }
 int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n) { ARG_CHECK(pol && n, "null"); *n = pol->np; return PPO_OK; }
 

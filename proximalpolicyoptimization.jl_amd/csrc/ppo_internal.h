@@ -79,6 +79,10 @@ struct ppo_policy_s {
     DevBuf<float> params;              // [np]
     DevBuf<float> w1p, w2p, w2tp;      // A-operand fragment order
     DevBuf<float> b1p, b2p, w3p, b3;   // accumulator-init / VALU packs
+    // bf16 compute mode (ppo_policy_set_dtype): bf16 fragment streams of the same parameters, rewritten by k_adam
+    int32_t dtype = 0;                 // PPO_DTYPE_F32 / PPO_DTYPE_BF16
+    DevBuf<uint16_t> w1b, w2b, w2tb;   // [HID/32][KS][64][8] A-operand fragments of v_mfma_f32_32x32x16_bf16
+    DevBuf<uint16_t> w3c, w3tb;        // layer 3 forward (compact rows 0..3) / backward ([HID][4])
     DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
     // training workspace
     DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4
@@ -153,6 +157,11 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                 int64_t B_global, double eps, double entropy_weight);
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+// bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
+struct FwdArgs;
+int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t B, int tps);
+int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+static inline int bf16_ks1(int F) { return (F + 15) / 16; }     // layer-1 k-steps of 16 (zero padded)
 int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);
 int32_t launch_adam(ppo_adam_s* o, float* hist2_or_null);
 int32_t launch_categorical(const float* probs, const float* u, int64_t B, int64_t A, int32_t* actions, float* psel,

@@ -85,7 +85,19 @@ __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, d
 }
 
 // ---------------------------------------------------------------- Adam + pack
-struct PackPtrs { float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3; };
+struct PackPtrs {
+    float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3;
+    // bf16 compute mode (null in fp32 mode): A-operand fragments of v_mfma_f32_32x32x16_bf16 (ppo_policy_bf16.hip)
+    uint16_t* w1b; uint16_t* w2b; uint16_t* w2tb; uint16_t* w3c; uint16_t* w3tb;
+};
+
+__device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // RNE
+// k-slot of contraction index kk (0..31) inside a 32-wide tile when the other operand is a packed accumulator tile:
+// k-step s = kk>>4, lane half hh and element jj such that 16s + 8(jj>>2) + 4hh + (jj&3) == kk
+__device__ __forceinline__ void acc_kslot(int kk, int& s, int& hh, int& jj) {
+    const int q = kk & 15;
+    s = kk >> 4; hh = (q >> 2) & 1; jj = 4 * (q >> 3) + (q & 3);
+}
 
 __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P, int64_t i, float x) {
     const int HID = L.HID, F = L.F, NT = L.NT;
@@ -93,6 +105,10 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
         const int io = (int)(i % HID), k = (int)(i / HID);
         const int hh = k / (F / 2), s = k % (F / 2);
         P.w1p[((size_t)((io >> 5) * (F / 8) + (s >> 2)) * 64 + (io & 31) + 32 * hh) * 4 + (s & 3)] = x;
+        if (P.w1b) {                                     // natural k order: k = 16*step + 8*half + element
+            const int KS1 = (F + 15) / 16;
+            P.w1b[((size_t)((io >> 5) * KS1 + (k >> 4)) * 64 + (io & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)] = to_bf16(x);
+        }
     } else if (i < L.offW2) {
         const int f = (int)(i - L.offb1), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         P.b1p[((f >> 5) * 2 + hh) * 16 + r] = x;
@@ -108,6 +124,14 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             const int s = f >> 1, hh = f & 1;
             P.w2tp[((size_t)((k >> 5) * (HID / 8) + (s >> 2)) * 64 + (k & 31) + 32 * hh) * 4 + (s & 3)] = x;
         }
+        if (P.w2b) {
+            const uint16_t xb = to_bf16(x);
+            int s, hh, jj;
+            acc_kslot(k & 31, s, hh, jj);                // forward: out f, contraction k against packed H1 tiles
+            P.w2b[((size_t)((f >> 5) * (HID / 16) + 2 * (k >> 5) + s) * 64 + (f & 31) + 32 * hh) * 8 + jj] = xb;
+            acc_kslot(f & 31, s, hh, jj);                // backward (W2^T): out k, contraction f against packed dZ2 tiles
+            P.w2tb[((size_t)((k >> 5) * (HID / 16) + 2 * (f >> 5) + s) * 64 + (k & 31) + 32 * hh) * 8 + jj] = xb;
+        }
     } else if (i < L.offW3) {
         const int f = (int)(i - L.offb2), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         P.b2p[((f >> 5) * 2 + hh) * 16 + r] = x;
@@ -116,6 +140,13 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
         const int oo = (int)(e & 3), k = (int)(e >> 2);
         const int kk = k & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         P.w3p[((size_t)(hh * NT + (k >> 5)) * 16 + r) * 4 + oo] = x;
+        if (P.w3c) {
+            const uint16_t xb = to_bf16(x);
+            int s, h2, jj;
+            acc_kslot(k & 31, s, h2, jj);                // forward: rows 0..3 of the layer-3 A operand, [step][half][o][8]
+            P.w3c[((size_t)((2 * (k >> 5) + s) * 2 + h2) * 4 + oo) * 8 + jj] = xb;
+            P.w3tb[(size_t)k * 4 + oo] = xb;             // backward: W3^T rows [HID][4]
+        }
     } else {
         P.b3[i - L.offb3] = x;
     }
@@ -157,6 +188,9 @@ static PackPtrs packs_of(ppo_policy_s* p) {
     PackPtrs P;
     P.w1p = p->w1p.p; P.w2p = p->w2p.p; P.w2tp = p->w2tp.p; P.b1p = p->b1p.p; P.b2p = p->b2p.p; P.w3p = p->w3p.p;
     P.b3 = p->b3.p;
+    const bool b = (p->dtype == PPO_DTYPE_BF16);
+    P.w1b = b ? p->w1b.p : nullptr; P.w2b = b ? p->w2b.p : nullptr; P.w2tb = b ? p->w2tb.p : nullptr;
+    P.w3c = b ? p->w3c.p : nullptr; P.w3tb = b ? p->w3tb.p : nullptr;
     return P;
 }
 

@@ -1,0 +1,600 @@
+// ppo_policy_bf16.hip -- bf16 compute mode of the policy MLP (BASELINE config 5: "bf16 MLP on MFMA + fp32 GAE").
+//
+// Same reference ops as ppo_policy_fwd.hip / ppo_policy_bwd.hip (action_probabilities / batch_action_probabilities,
+// test/quad_game_utilities.jl:65-79 over SimplePolicy, test/policy.jl:9-31; Zygote gradient of step_batch!,
+// src/train.jl:54-84), with the three Dense contractions on v_mfma_f32_32x32x16_bf16:
+//   weights and layer inputs are bfloat16 (RNE from the fp32 master parameters / fp32 activations), products are
+//   exact, accumulation, bias, leakyrelu, softmax, sampling, loss and Adam are fp32 as in the fp32 mode.
+//   Saved activations are bf16; the backward signals (dY, dZ2, dZ1) are rounded to bf16 before they enter an MFMA.
+// The reference is Float32 only: this mode has no reference counterpart beyond "same function at lower precision";
+// the tests check it against a CPU restatement with the same rounding points and float64 accumulation (tolerances
+// stated there).
+//
+// gfx950 mapping, forward: one wave per 32-row tile, Y^T = W * X^T as in the fp32 kernel, so the 32x32 accumulators
+// of a layer (row on the lane, 16 features in registers) become the B operands of the next layer after one
+// v_cvt_pk_bf16_f32 per register pair (k order permuted: element j of lane half h of k-step s is feature
+// 16s + 8(j>>2) + 4h + (j&3); the packed weight fragments carry the same permutation).  A bf16 MFMA retires
+// 16x the flops of the fp32 one per cycle, so the weight stream has to come from LDS: W2 (128 KiB as bf16 for
+// HID = 256) is staged once per workgroup, one ds_read_b128 per MFMA; W1 (36 KiB) streams through L1; layer 3
+// (HID x 4) is two more MFMAs per feature tile with a zero-padded A operand instead of 64 VALU FMAs.
+// Backward: a workgroup of HID/32 waves walks tiles; wave w owns feature tile w of every weight gradient
+// (accumulators resident all launch).  The lane-is-row tiles (dZ2, H1, dZ1, H2) are written once as row-major
+// bf16 images into LDS and come back TRANSPOSED through ds_read_b64_tr_b16 as the operands of the products that
+// contract over the 32 rows (dW2, dW1, dW3); dH1 = W2^T dZ2 takes dZ2 lane-linear in accumulator-fragment order.
+#include "ppo_policy_tail.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t d) { return __uint_as_float(d << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t d) { return __uint_as_float(d & 0xFFFF0000u); }
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// leakyrelu(x) = max(x, 0.01x) for slope < 1 (same value as x > 0 ? x : 0.01x for every finite x)
+__device__ __forceinline__ float lrelu_max(float x) { return fmaxf(x, 0.01f * x); }
+// accumulator tile -> two B/A operand fragments (k-steps 0 and 1) of the next product
+__device__ __forceinline__ void pack_tile(const f32x16& acc, uint4 (&out)[2]) {
+    out[0] = make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
+    out[1] = make_uint4(pack_bf16(acc[8], acc[9]), pack_bf16(acc[10], acc[11]), pack_bf16(acc[12], acc[13]), pack_bf16(acc[14], acc[15]));
+}
+__device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// ================================================================ forward
+template <int F, int HID>
+struct FwdB {
+    static constexpr int NT = HID / 32, NS = HID / 16, KS1 = (F + 15) / 16;
+    static constexpr int W2_U4 = NT * NS * 64;            // uint4 elements of the staged W2 fragments
+    static constexpr int W3_U4 = NS * 8 + 1;              // compact layer-3 rows + one zero block
+    static constexpr size_t lds_bytes = (size_t)(W2_U4 + W3_U4) * 16 + (size_t)NT * 8 * 16 * 2;
+};
+
+template <int F, int HID, int MODE, int TPS>
+__global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
+    using C = FwdB<F, HID>;
+    constexpr int NT = C::NT, NS = C::NS, KS1 = C::KS1;
+    static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) uint4 smem_u4[];
+    uint4* const sW2 = smem_u4;
+    uint4* const sW3 = sW2 + C::W2_U4;
+    float4* const sB1 = reinterpret_cast<float4*>(sW3 + C::W3_U4);
+    float4* const sB2 = sB1 + NT * 8;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < C::W2_U4; i += 512) sW2[i] = a.w2b[i];
+    for (int i = tid; i < NS * 8; i += 512) sW3[i] = a.w3c[i];
+    if (tid == 0) sW3[NS * 8] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < NT * 8; i += 512) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    __syncthreads();
+    // layer-3 A operand: rows 0..3 of the 32-row operand tile are W3, the rest zero (lanes j >= 4 read the zero block)
+    const int w3_lane = (j < 4) ? (h * 4 + j) : -1;
+
+    for (int64_t state = (int64_t)blockIdx.x * 8 + w; state < a.B; state += (int64_t)gridDim.x * 8) {
+        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
+        const uint32_t act = a.active[sid];
+        float l[TPS][4];
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) l[tt][0] = l[tt][1] = l[tt][2] = l[tt][3] = 0.0f;
+#pragma unroll 1
+        for (int ts = 0; ts < TPS; ++ts) {
+            const int64_t tile = state * TPS + ts;
+            // ---- state rows -> layer-1 B operands: lane (row j, half h) holds features 16s + 8h .. +7 of k-step s
+            const int8_t* row = a.states + ((size_t)sid * TPS + ts) * 32 * F + (size_t)j * F;
+            uint4 xs[KS1];
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const int off = 16 * s + 8 * h;
+                uint2 d = make_uint2(0u, 0u);
+                if (off < F) d = *reinterpret_cast<const uint2*>(row + off);
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f[i] = (float)(int)(int8_t)(d.x >> (8 * i));
+                    f[4 + i] = (float)(int)(int8_t)(d.y >> (8 * i));
+                }
+                xs[s] = make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+            }
+            // ---- layer 1 (W1 fragments through L1: 1 KiB per wave load, PF1 of them in flight in a register ring;
+            // sched_barrier keeps hipcc from hoisting the whole 40-fragment stream into registers)
+            uint4 h1p[NT][2];
+            {
+                constexpr int NG = NT * KS1, PF1 = (NG < 6) ? NG : 6;
+                const uint4* wp = a.w1b + lane;
+                uint4 ring[PF1];
+#pragma unroll
+                for (int g = 0; g < PF1; ++g) ring[g] = wp[(size_t)g * 64];
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b = sB1[(o * 2 + h) * 4 + q];
+                        acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                    }
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) {
+                        const int g = o * KS1 + s;
+                        const uint4 wv = ring[g % PF1];
+                        if (g + PF1 < NG) ring[g % PF1] = wp[(size_t)(g + PF1) * 64];
+                        acc = mfma_bf16(wv, xs[s], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
+                    pack_tile(acc, h1p[o]);
+                    if (MODE == 2) {
+                        a.act1b[((size_t)tile * NT + o) * 128 + lane] = h1p[o][0];
+                        a.act1b[((size_t)tile * NT + o) * 128 + 64 + lane] = h1p[o][1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- layer 2 (W2 fragments from LDS) + layer 3 (two MFMAs per feature tile)
+            f32x16 acc3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+#pragma unroll 1
+            for (int o = 0; o < NT; ++o) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = sB2[(o * 2 + h) * 4 + q];
+                    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                }
+                const uint4* wo = sW2 + (size_t)o * NS * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc = mfma_bf16(wo[(2 * t) * 64], h1p[t][0], acc);
+                    acc = mfma_bf16(wo[(2 * t + 1) * 64], h1p[t][1], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
+                uint4 h2p[2];
+                pack_tile(acc, h2p);
+                if (MODE == 2) {
+                    a.act2b[((size_t)tile * NT + o) * 128 + lane] = h2p[0];
+                    a.act2b[((size_t)tile * NT + o) * 128 + 64 + lane] = h2p[1];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int idx = (w3_lane >= 0) ? ((2 * o + s) * 8 + w3_lane) : NS * 8;
+                    acc3 = mfma_bf16(sW3[idx], h2p[s], acc3);
+                }
+            }
+            // logits of row j sit in accumulator registers 0..3 of lane j (lane half 0): hand them to both halves
+            float lg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lg[i] = __shfl(acc3[i], j) + a.b3[i];
+#pragma unroll
+            for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) l[tt][i] = (tt == ts) ? lg[i] : l[tt][i];
+        }
+        policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h);
+    }
+}
+
+template <int MODE>
+static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B, int tps) {
+    const int64_t need = (B + 7) / 8;
+    const unsigned grid = (unsigned)(need < 256 ? need : 256);
+#define LAUNCHB(FF, HH, TT)                                                                                          \
+    do {                                                                                                             \
+        const size_t lds = FwdB<FF, HH>::lds_bytes;                                                                  \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<FF, HH, MODE, TT>,                            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_policy_fwd_bf16<FF, HH, MODE, TT>), dim3(grid), dim3(512), lds, ppo_stream(), args);   \
+    } while (0)
+    if (p->F == 72 && p->HID == 256 && tps == 1) LAUNCHB(72, 256, 1);
+    else if (p->F == 72 && p->HID == 256 && tps == 4) LAUNCHB(72, 256, 4);
+    else if (p->F == 72 && p->HID == 128 && tps == 1) LAUNCHB(72, 128, 1);
+    else if (p->F == 72 && p->HID == 128 && tps == 4) LAUNCHB(72, 128, 4);
+    else { ppo_set_error("unsupported policy/state shape (F,HID,H) for the gfx950 bf16 kernels"); return PPO_ERR_UNSUPPORTED; }
+#undef LAUNCHB
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& a, int mode, int64_t B, int tps) {
+    a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
+    a.act1b = (uint4*)p->act1.p; a.act2b = (uint4*)p->act2.p;
+    if (mode == 0) return dispatch_fwd_bf16<0>(p, a, B, tps);
+    if (mode == 1) return dispatch_fwd_bf16<1>(p, a, B, tps);
+    return dispatch_fwd_bf16<2>(p, a, B, tps);
+}
+
+// ================================================================ backward
+struct BwdBArgs {
+    const int8_t* states; const int32_t* idx; int32_t B;   // B = number of 32-row tiles (states * tps), < 2^31
+    int tps_shift;                                          // tiles per state = 1 << tps_shift (H = 32 or 128)
+    const uint4* act1b; const uint4* act2b; const float4* dY;
+    const uint4* w2tb; const uint2* w3tb;
+    uint4* z1f; uint4* xf;                                  // operand fragments handed to k_policy_dw1_bf16
+    float* slabs; size_t slab_stride;
+};
+
+// The weight-gradient accumulators decide the shape of the backward pass: dW2 (HID x HID) and dW1 (HID x F) need
+// 22 accumulator tiles = 352 registers per SIMD for HID = 256 -- two waves per SIMD cannot hold both next to their
+// working set, and one wave with > 256 accumulator registers spills.  So the pass is two kernels:
+//   k_policy_bwd_bf16  workgroup of 4 waves, one per SIMD with the whole register file; wave w owns feature tiles
+//                      w*FT .. w*FT+FT-1 of dW2 (256 accumulator registers = the AGPR half for HID = 256) and the
+//                      small grads.  It also emits, per tile, dZ1^T and X as ready-made MFMA operand fragments.
+//   k_policy_dw1_bf16  dW1 += dZ1^T X from those fragments: no LDS, no barriers, pure load + MFMA (the fragments
+//                      are 88 MB per 4096-state minibatch, written and re-read through the 256 MB Infinity Cache).
+template <int F, int HID>
+struct BwdB {
+    static constexpr int NT = HID / 32, NS = HID / 16, FP = ((F + 31) / 32) * 32, NI = FP / 32;
+    static constexpr int NW = 4, FT = NT / NW;            // waves per workgroup (one per SIMD), feature tiles per wave
+    static_assert(NT % NW == 0, "feature tiles per wave");
+    static constexpr int ST = 2 * HID + 64;               // image row stride (bytes): 16 dwords mod 64 -> the 4 rows of a
+    static constexpr int STX = 2 * FP;                    //   transposed-read block sit on different bank quarters
+    static_assert((ST / 4) % 64 == 16 || (ST / 4) % 64 == 48, "image stride");
+    static_assert((STX / 4) % 64 == 16 || (STX / 4) % 64 == 48, "X image stride");
+    static constexpr int IMG = 32 * ST;
+    static constexpr int oZ2 = 0, oH1 = IMG, oZ1 = 2 * IMG, oH2 = 3 * IMG, oZF = 4 * IMG, oX = oZF + NS * 1024,
+                         oDY = oX + 32 * STX, total = oDY + 512;
+};
+
+// two transposed 4x16 block reads -> one 32x32x16 operand fragment (8 consecutive rows of the lane's column)
+__device__ __forceinline__ uint4 tr_frag(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    const s16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    const uint2 a = __builtin_bit_cast(uint2, u0), b = __builtin_bit_cast(uint2, u1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ float sum_frag(const uint4& v) {
+    return ((bf16_lo(v.x) + bf16_hi(v.x)) + (bf16_lo(v.y) + bf16_hi(v.y))) + ((bf16_lo(v.z) + bf16_hi(v.z)) + (bf16_lo(v.w) + bf16_hi(v.w)));
+}
+
+template <int F, int HID>
+__global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
+    using C = BwdB<F, HID>;
+    constexpr int NT = C::NT, NS = C::NS, NI = C::NI, FT = C::FT, ST = C::ST, STX = C::STX, NTHR = 256;
+    constexpr int XDW = 32 * F / 4, XPD = (XDW + NTHR - 1) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* const imgZ2 = smem_c + C::oZ2;
+    char* const imgH1 = smem_c + C::oH1;
+    char* const imgZ1 = smem_c + C::oZ1;
+    char* const imgH2 = smem_c + C::oH2;
+    uint4* const sZF = reinterpret_cast<uint4*>(smem_c + C::oZF);
+    char* const imgX = smem_c + C::oX;
+    float* const sDY = reinterpret_cast<float*>(smem_c + C::oDY);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // zero the padded X image once (columns >= F are never written afterwards)
+    for (int i = tid; i < 32 * STX / 4; i += NTHR) reinterpret_cast<uint32_t*>(imgX)[i] = 0u;
+
+    f32x16 accW2[FT][NT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW2[i][kt][r] = 0.0f;
+    float db1[FT], db2[FT], dw3[FT][4], db3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < FT; ++i) { db1[i] = db2[i] = 0.f; dw3[i][0] = dw3[i][1] = dw3[i][2] = dw3[i][3] = 0.f; }
+
+    // A operands of dH2^T = W3^T dY^T for this wave's feature tiles: k = output index o (4 of the 16 k-slots used)
+    uint4 a3[FT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i) {
+        a3[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (h == 0) { const uint2 t = a.w3tb[32 * (w * FT + i) + j]; a3[i].x = t.x; a3[i].y = t.y; }
+    }
+
+    // image addressing.  Row-major [32 rows][cols] bf16, 8-byte chunk cc = col/4 stored at chunk cc ^ ((row>>1)&7):
+    // the 16 lanes of a ds_write_b64 group (16 consecutive rows, same chunk) then hit 16 different bank pairs.
+    // write side: lane (row j, half h) owns chunks 8*tile + 2g + h, g = 0..3
+    const int wsw = (j >> 1) & 7;
+    const int wrow = j * ST;
+    // transposed-read side (operand lane l: column l&31, rows 8h + 4u + q of k-step s; q = (l&15)>>2 supplies the row,
+    // p = l&3 the 4-column chunk, (l>>4)&1 the 16-column block of the 32-column tile)
+    const int tq = (lane & 15) >> 2, tcc = 4 * ((lane >> 4) & 1) + (lane & 3);
+    int tro[2], trx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = 8 * h + 4 * u + tq;
+        tro[u] = r * ST + 8 * (tcc ^ ((r >> 1) & 7));     // + 16*s*ST + 64*tile   (tile = 32-column tile index)
+        trx[u] = r * STX + 8 * tcc;                        // X image: no swizzle
+    }
+
+    // next tile's inputs, fetched one tile ahead (one wave per SIMD: nobody else hides the HBM latency)
+    uint4 nh2[FT][2], nh1[FT][2];
+    float4 ndy;
+    uint32_t nx[XPD];
+    auto prefetch = [&](int t) {
+        const int sidx = __builtin_amdgcn_readfirstlane(a.idx[t >> a.tps_shift]);
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const size_t base = ((size_t)t * NT + (w * FT + i)) * 128 + lane;
+            nh2[i][0] = a.act2b[base]; nh2[i][1] = a.act2b[base + 64];
+            nh1[i][0] = a.act1b[base]; nh1[i][1] = a.act1b[base + 64];
+        }
+        ndy = a.dY[(size_t)t * 32 + j];
+        const uint32_t* xs = reinterpret_cast<const uint32_t*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
+#pragma unroll
+        for (int i = 0; i < XPD; ++i) {
+            const int d = tid + i * NTHR;
+            nx[i] = d < XDW ? xs[d] : 0u;
+        }
+    };
+    if ((int)blockIdx.x < a.B) prefetch((int)blockIdx.x);
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        // ================= phase A: dZ2 = (W3^T dY) . lrelu'(H2), images (inputs were fetched one tile ahead)
+        const float4 dy = ndy;
+#pragma unroll
+        for (int i = 0; i < XPD; ++i) {
+            const int d = tid + i * NTHR;
+            if (d < XDW) {
+                const uint32_t v = nx[i];
+                const int row = d / (F / 4), c4 = d % (F / 4);
+                *reinterpret_cast<uint2*>(imgX + row * STX + c4 * 8) =
+                    make_uint2(pack_bf16((float)(int)(int8_t)(v), (float)(int)(int8_t)(v >> 8)),
+                               pack_bf16((float)(int)(int8_t)(v >> 16), (float)(int)(int8_t)(v >> 24)));
+            }
+        }
+        const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
+        if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
+        const uint4 bdy = (h == 0) ? make_uint4(dy01, dy23, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < FT; ++i) {
+            const int ft = w * FT + i;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            acc = mfma_bf16(a3[i], bdy, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t d = dw(nh2[i][r >> 3], (r >> 1) & 3);
+                const float hv = (r & 1) ? bf16_hi(d) : bf16_lo(d);
+                acc[r] = acc[r] * (hv > 0.0f ? 1.0f : 0.01f);
+            }
+            uint4 zf[2];
+            pack_tile(acc, zf);
+            sZF[(2 * ft) * 64 + lane] = zf[0];
+            sZF[(2 * ft + 1) * 64 + lane] = zf[1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
+                *reinterpret_cast<uint2*>(imgZ2 + off) = make_uint2(dw(zf[g >> 1], 2 * (g & 1)), dw(zf[g >> 1], 2 * (g & 1) + 1));
+                *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
+                *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[i][g >> 1], 2 * (g & 1)), dw(nh1[i][g >> 1], 2 * (g & 1) + 1));
+            }
+        }
+        // first W2^T fragments of phase B (L2-resident, independent of the barrier): issued now so they land under it
+        constexpr int PFB = 4;                                       // k-steps in flight (FT fragments each)
+        uint4 ring[PFB][FT];
+        const uint4* wt = a.w2tb + (size_t)(w * FT) * NS * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < PFB; ++g)
+#pragma unroll
+            for (int i = 0; i < FT; ++i) ring[g][i] = wt[(size_t)(i * NS + g) * 64];
+        __syncthreads();
+        // ================= phase B: dH1^T[k-tiles of this wave] = W2^T dZ2^T, dZ1 = dH1 . lrelu'(H1) -> image
+        {
+            // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A) and
+            // land under the MFMAs of phases B and C
+            const int ntile = (tile + (int)gridDim.x < a.B) ? tile + (int)gridDim.x : tile;     // harmless re-load on the last tile
+            prefetch(ntile);
+            f32x16 acc[FT];
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint4 bz = sZF[s * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    const uint4 wv = ring[s % PFB][i];
+                    if (s + PFB < NS) ring[s % PFB][i] = wt[(size_t)(i * NS + s + PFB) * 64];
+                    acc[i] = mfma_bf16(wv, bz, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
+                const int ft = w * FT + i;
+                uint2 hc[4];         // H1 of this feature tile, back from the image written in phase A (lane = row again)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) hc[g] = *reinterpret_cast<const uint2*>(imgH1 + wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t d = (r & 2) ? hc[r >> 2].y : hc[r >> 2].x;
+                    const float hv = (r & 1) ? bf16_hi(d) : bf16_lo(d);
+                    acc[i][r] = acc[i][r] * (hv > 0.0f ? 1.0f : 0.01f);
+                }
+                uint4 z1[2];
+                pack_tile(acc[i], z1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
+                    *reinterpret_cast<uint2*>(imgZ1 + off) = make_uint2(dw(z1[g >> 1], 2 * (g & 1)), dw(z1[g >> 1], 2 * (g & 1) + 1));
+                }
+            }
+        }
+        // a wave's dZ1 columns are read back (transposed) by that wave only: its own LDS writes just have to land.
+        // Phase C writes no LDS, so the other waves' phase-B reads need no barrier here; the one at the end of the
+        // tile keeps the next phase A from overwriting the images early.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ================= phase C: products that contract over the 32 rows (operands: transposed image reads)
+        {
+            uint4 az[FT][2];
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    az[i][s] = tr_frag(imgZ2 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ2 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+                    db2[i] += sum_frag(az[i][s]);
+                }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                uint4 b[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b[s] = tr_frag(imgH1 + tro[0] + 16 * s * ST + 64 * kt, imgH1 + tro[1] + 16 * s * ST + 64 * kt);
+#pragma unroll
+                for (int i = 0; i < FT; ++i)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
+            }
+            // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
+            // MFMA tile that would be 7/8 zero padding): lane (f, h) holds rows 16s + 8h + e of column f
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 hb = tr_frag(imgH2 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgH2 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t d = dw(hb, e >> 1);
+                        const float hv = (e & 1) ? bf16_hi(d) : bf16_lo(d);
+                        const float4 y = *reinterpret_cast<const float4*>(sDY + (16 * s + 8 * h + e) * 4);
+                        dw3[i][0] = fmaf(y.x, hv, dw3[i][0]); dw3[i][1] = fmaf(y.y, hv, dw3[i][1]);
+                        dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
+                    }
+                }
+            // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
+            // for k_policy_dw1_bf16
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 z = tr_frag(imgZ1 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ1 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+                    db1[i] += sum_frag(z);
+                    a.z1f[(((size_t)tile * NT + (w * FT + i)) * 2 + s) * 64 + lane] = z;
+                }
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
+                const int it = w * FT + i;                     // wave-uniform
+                if (it < NI) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        a.xf[(((size_t)tile * NI + it) * 2 + s) * 64 + lane] =
+                            tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it);
+                }
+            }
+            if (tid < 4) {
+                float s = 0.f;
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                db3 += s;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================= slab (same fragment order as the fp32 kernel: k_grad_reduce maps it to Flux order);
+    // the dW1 region is written by k_policy_dw1_bf16
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    float* sW2 = slab;
+    float* sW1 = sW2 + (size_t)HID * HID;
+    float* sb1 = sW1 + (size_t)HID * C::FP;
+    float* sb2 = sb1 + HID;
+    float* sw3 = sb2 + HID;
+    float* sb3 = sw3 + HID * 4;
+#pragma unroll
+    for (int i = 0; i < FT; ++i) {
+        const int ft = w * FT + i;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sW2[((size_t)(ft * NT + kt) * 16 + r) * 64 + lane] = accW2[i][kt][r];
+        const float b1 = db1[i] + __shfl_xor(db1[i], 32), b2 = db2[i] + __shfl_xor(db2[i], 32);
+        float d3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) d3[o] = dw3[i][o] + __shfl_xor(dw3[i][o], 32);
+        if (h == 0) {
+            const int f = 32 * ft + j;
+            sb1[f] = b1; sb2[f] = b2;
+            *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(d3[0], d3[1], d3[2], d3[3]);
+        }
+    }
+    if (tid < 4) sb3[tid] = db3;
+}
+
+// dW1[k][i] += sum_rows dZ1[k][row] X[row][i] from the operand fragments of k_policy_bwd_bf16.  Same tile -> workgroup
+// assignment, so workgroup g fills the dW1 region of slab g.  Wave w owns k-tile w (NI accumulator tiles).
+template <int F, int HID>
+__global__ __launch_bounds__(HID * 2) void k_policy_dw1_bf16(BwdBArgs a) {
+    using C = BwdB<F, HID>;
+    constexpr int NT = C::NT, NI = C::NI;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x16 acc[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[it][r] = 0.0f;
+    for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        uint4 z[2], x[NI][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) z[s] = a.z1f[(((size_t)tile * NT + w) * 2 + s) * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) x[it][s] = a.xf[(((size_t)tile * NI + it) * 2 + s) * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[it] = mfma_bf16(z[s], x[it][s], acc[it]);
+    }
+    float* sW1 = a.slabs + (size_t)blockIdx.x * a.slab_stride + (size_t)HID * HID;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = acc[it][r];
+}
+
+int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
+    BwdBArgs a;
+    const int tps = ro->H / 32;
+    ARG_CHECK((tps == 1 || tps == 4) && B * tps < ((int64_t)1 << 30), "bf16 backward: H must be 32 or 128 and the minibatch below 2^30 tiles");
+    a.tps_shift = (tps == 4) ? 2 : 0;
+    a.states = ro->states.p; a.idx = idx_dev; a.B = (int32_t)(B * tps);
+    a.act1b = (const uint4*)p->act1.p; a.act2b = (const uint4*)p->act2.p; a.dY = (const float4*)p->dY.p;
+    a.w2tb = (const uint4*)p->w2tb.p; a.w3tb = (const uint2*)p->w3tb.p;
+    // the fp32 mode's activation buffers are twice the size the bf16 activations need: the operand fragments for the
+    // dW1 kernel live in their upper halves (z1f behind act1b, xf behind act2b; NI <= NT)
+    a.z1f = (uint4*)p->act1.p + (size_t)a.B * (p->HID / 32) * 128;
+    a.xf = (uint4*)p->act2.p + (size_t)a.B * (p->HID / 32) * 128;
+    a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    const int nwg = (int)(a.B < 256 ? a.B : 256);
+    p->nwg_bwd = nwg;
+#define LAUNCHB(FF, HH)                                                                                           \
+    do {                                                                                                          \
+        static_assert(BwdB<FF, HH>::NI <= BwdB<FF, HH>::NT, "X fragments are emitted by waves 0..NI-1");          \
+        const size_t lds = BwdB<FF, HH>::total;                                                                   \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_bf16<FF, HH>,                                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        {                                                                                                         \
+            ProfScope ps("k_policy_bwd");                                                                         \
+            hipLaunchKernelGGL((k_policy_bwd_bf16<FF, HH>), dim3(nwg), dim3(256), lds, ppo_stream(), a);       \
+        }                                                                                                         \
+        {                                                                                                         \
+            ProfScope ps("k_policy_dw1");                                                                         \
+            hipLaunchKernelGGL((k_policy_dw1_bf16<FF, HH>), dim3(nwg), dim3(HH * 2), 0, ppo_stream(), a);         \
+        }                                                                                                         \
+    } while (0)
+    if (p->F == 72 && p->HID == 256) LAUNCHB(72, 256);
+    else if (p->F == 72 && p->HID == 128) LAUNCHB(72, 128);
+    else { ppo_set_error("unsupported policy shape (F,HID) for the gfx950 bf16 kernels"); return PPO_ERR_UNSUPPORTED; }
+#undef LAUNCHB
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}

@@ -430,6 +430,7 @@ static size_t bwd_lds_bytes() {
 }
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
+    if (p->dtype == PPO_DTYPE_BF16) return launch_policy_bwd_bf16(p, ro, idx_dev, B);
     BwdArgs a;
     a.tps = ro->H / 32;
     a.states = ro->states.p; a.idx = idx_dev; a.B = B * a.tps;

@@ -16,8 +16,7 @@
 //
 // MFMA-bound: 2*(F*HID + HID*HID)*32 flop per state on the matrix pipe; layer 3 (HID x 4) is a VALU
 // dot-product epilogue.
-#include "ppo_internal.h"
-#include "ppo_device.h"
+#include "ppo_policy_tail.h"
 
 // activation stores of the train forward: tuning knobs for A/B builds (defaults are the shipped configuration)
 #ifndef PPO_FWD_STORE
@@ -37,40 +36,6 @@ static __device__ __forceinline__ void act_store_nt(float4* p, float4 v) {
 #else
 #define ACT_STORE(ptr, val) (*(ptr) = (val))
 #endif
-
-struct FwdArgs {
-    // inputs
-    const int8_t* states;      // MODE 0/1: [B][H][F]; MODE 2: rollout states base (gathered by idx)
-    const uint32_t* active;    // same indexing as states
-    const int32_t* idx;        // MODE 2: transition id per tile
-    int64_t B;
-    unsigned long long* stamps;   // diagnostic build only (-DPPO_FWD_STAMP)
-    int wg_sync;               // 1: every wave of a workgroup runs the same number of tiles -> per-chunk barriers allowed
-    const float4* w1p; const float4* w2p; const float4* b1p; const float4* b2p; const float4* w3p; const float* b3;
-    // MODE 0
-    float* probs_out;
-    // MODE 1
-    const uint32_t* tick; int64_t global_offset; uint32_t k0, k1;
-    int32_t* actions_out; float* psel_out; float* full_probs; int32_t* err;
-    // MODE 2
-    float4* act1; float4* act2; float4* dY; double* loss_terms;
-    const int32_t* actions; const float* p_old; const float* adv;
-    double eps; float c_over_B; float inv_B;
-};
-
-__device__ __forceinline__ float wave32_max(float v) {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave32_sum(float v) {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
 
 // waves per SIMD: the HID=256 / F=216 instantiations need more than 256 VGPRs (128 for the layer-1
 // accumulators + operands in flight), so they run one wave per SIMD with the whole 512-entry file.
@@ -95,7 +60,6 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #define PPO_FWD_OUNROLL 1
 #endif
     constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PPO_FWD_PF : 4;   // weight-fragment groups kept in flight per wave
-    constexpr int A = 128 * TPS;
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;           // half-edge row inside the tile
@@ -270,110 +234,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
         }
 
         FSTAMP(4);
-        // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
-        bool on[TPS];
-        float m = -INFINITY;
-#pragma unroll
-        for (int ts = 0; ts < TPS; ++ts) {
-            on[ts] = (act >> (8 * ts + (j >> 2))) & 1u;
-            if (on[ts]) m = fmaxf(m, fmaxf(fmaxf(l[ts][0], l[ts][1]), fmaxf(l[ts][2], l[ts][3])));
-        }
-        m = wave32_max(m);
-        float p[TPS][4];
-        float ssum = 0.0f;
-#pragma unroll
-        for (int ts = 0; ts < TPS; ++ts) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[ts][i] = on[ts] ? exp_dev(l[ts][i] - m) : 0.0f;
-            const float st = ((p[ts][0] + p[ts][1]) + p[ts][2]) + p[ts][3];
-            ssum = (ts == 0) ? st : ssum + st;                 // tile partials in tile order, then the butterfly
-        }
-        ssum = wave32_sum(ssum);
-#pragma unroll
-        for (int ts = 0; ts < TPS; ++ts)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[ts][i] = p[ts][i] / ssum;
-
-        if (MODE == 0) {
-            if (h == 0) {
-#pragma unroll
-                for (int ts = 0; ts < TPS; ++ts)
-                    reinterpret_cast<float4*>(a.probs_out)[((size_t)state * TPS + ts) * 32 + j] =
-                        make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
-            }
-        }
-        if (MODE == 1) {
-            // rand(Categorical(p)): sequential fp32 inverse-CDF walk, same uniform as the oracle
-            uint32_t rnd[4];
-            philox4x32_10((uint32_t)(a.global_offset + state), a.tick[state], 0u, 0u, a.k0, a.k1, rnd);
-            const float u = u01_from_u32(rnd[0]);
-            float cp = readlane_f(p[0][0], 0);
-            int ia = 0;
-#pragma unroll
-            for (int q = 1; q < A; ++q) {
-                const float pa = readlane_f(p[q >> 7][q & 3], (q & 127) >> 2);
-                const bool take = cp <= u;
-                cp = take ? cp + pa : cp;
-                ia = take ? q : ia;
-            }
-            float cand = 0.0f;
-#pragma unroll
-            for (int ts = 0; ts < TPS; ++ts)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cand = ((ia >> 7) == ts && (ia & 3) == i) ? p[ts][i] : cand;
-            const float psel = __shfl(cand, (ia & 127) >> 2);
-            if (lane == 0) {
-                if (!(psel > 0.0f)) atomicOr(a.err, 8);     // @assert ap[a] > 0.0
-                a.actions_out[state] = ia;
-                a.psel_out[state] = psel;
-            }
-            if (a.full_probs && h == 0) {
-#pragma unroll
-                for (int ts = 0; ts < TPS; ++ts)
-                    reinterpret_cast<float4*>(a.full_probs)[((size_t)state * TPS + ts) * 32 + j] =
-                        make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
-            }
-        }
-        if (MODE == 2) {
-            const int ab = a.actions[sid];
-            const float po = a.p_old[sid];
-            const float adv = a.adv[sid];
-            float cand = 0.0f;
-#pragma unroll
-            for (int ts = 0; ts < TPS; ++ts)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cand = ((ab >> 7) == ts && (ab & 3) == i) ? p[ts][i] : cand;
-            const float ps = __shfl(cand, (ab & 127) >> 2);
-            const float gain = ps / po * adv;                                    // src/train.jl:39 (Float32)
-            const double clip = adv >= 0.0f ? (1.0 + a.eps) * (double)adv : (1.0 - a.eps) * (double)adv;   // :1-7
-            const bool unclipped = (double)gain < clip;
-            const double minval = unclipped ? (double)gain : clip;
-            const float sA = 1e-8f / (float)A;                                   // smooth/size(probs,1)  :22
-            float lg[TPS][4], hl = 0.0f;
-#pragma unroll
-            for (int ts = 0; ts < TPS; ++ts)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const float sp = p[ts][i] + sA; lg[ts][i] = logf(sp); hl += sp * lg[ts][i]; }
-            hl = wave32_sum(hl);
-            float dp[TPS][4], dot = 0.0f;
-            const float dsel = unclipped ? -(a.inv_B * adv / po) : 0.0f;
-#pragma unroll
-            for (int ts = 0; ts < TPS; ++ts)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dp[ts][i] = a.c_over_B * (lg[ts][i] + 1.0f) + ((128 * ts + 4 * j + i == ab) ? dsel : 0.0f);
-                    dot += p[ts][i] * dp[ts][i];
-                }
-            dot = wave32_sum(dot);
-            if (h == 0) {
-#pragma unroll
-                for (int ts = 0; ts < TPS; ++ts)
-                    a.dY[((size_t)state * TPS + ts) * 32 + j] =
-                        make_float4(p[ts][0] * (dp[ts][0] - dot), p[ts][1] * (dp[ts][1] - dot),
-                                    p[ts][2] * (dp[ts][2] - dot), p[ts][3] * (dp[ts][3] - dot));
-            }
-            if (lane == 0) { a.loss_terms[state * 2] = minval; a.loss_terms[state * 2 + 1] = (double)(-hl); }
-        }
+        policy_tail<MODE, TPS, false>(a, state, sid, act, l, lane, j, h);
         FSTAMP(5);
     }
 #ifdef PPO_FWD_STAMP
@@ -446,6 +307,7 @@ int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uin
     fill_weights(p, a);
     a.states = states_dev; a.active = active_dev; a.B = B; a.probs_out = probs_dev;
     ProfScope ps("k_policy_fwd_probs");
+    if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 0, B, H / 32);
     return dispatch_fwd<0>(p, a, B, H / 32);
 }
 
@@ -457,6 +319,7 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
     a.tick = e->tick.p; a.global_offset = e->global_offset; a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32);
     a.actions_out = actions_out; a.psel_out = psel_out; a.full_probs = full_probs_or_null; a.err = e->err.p;
     ProfScope ps("k_policy_fwd_rollout");
+    if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 1, e->N, e->H / 32);
     return dispatch_fwd<1>(p, a, e->N, e->H / 32);
 }
 
@@ -469,6 +332,7 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
     a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = ro->returns.p;
     a.eps = eps; a.c_over_B = (float)(entropy_weight / (double)B_global); a.inv_B = (float)(1.0 / (double)B_global);
     ProfScope ps("k_policy_fwd_train");
+    if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 2, B, ro->H / 32);
     return dispatch_fwd<2>(p, a, B, ro->H / 32);
 }
 

@@ -1,0 +1,162 @@
+// ppo_policy_tail.h -- the part of the policy forward that both compute modes (fp32 MFMA, bf16 MFMA) share:
+// kernel arguments, and everything behind the 4 logits per lane of a state -- masked softmax
+// (test/quad_game_utilities.jl:68-69,76-77), rand(Categorical) + ap[a] > 0 (src/collect_rollouts.jl:6-7), and the
+// loss / dlogits of ppo_loss_with_entropy (src/train.jl:21-26,35-46).  All fp32 in both modes.
+#pragma once
+#include "ppo_internal.h"
+#include "ppo_device.h"
+
+struct FwdArgs {
+    // inputs
+    const int8_t* states;      // MODE 0/1: [B][H][F]; MODE 2: rollout states base (gathered by idx)
+    const uint32_t* active;    // same indexing as states
+    const int32_t* idx;        // MODE 2: transition id per tile
+    int64_t B;
+    unsigned long long* stamps;   // diagnostic build only (-DPPO_FWD_STAMP)
+    int wg_sync;               // 1: every wave of a workgroup runs the same number of tiles -> per-chunk barriers allowed
+    const float4* w1p; const float4* w2p; const float4* b1p; const float4* b2p; const float4* w3p; const float* b3;
+    // MODE 0
+    float* probs_out;
+    // MODE 1
+    const uint32_t* tick; int64_t global_offset; uint32_t k0, k1;
+    int32_t* actions_out; float* psel_out; float* full_probs; int32_t* err;
+    // MODE 2
+    float4* act1; float4* act2; float4* dY; double* loss_terms;
+    const int32_t* actions; const float* p_old; const float* adv;
+    double eps; float c_over_B; float inv_B;
+    // bf16 compute mode (ppo_policy_bf16.hip): bf16 fragment streams and bf16 saved activations
+    const uint4* w1b; const uint4* w2b; const uint4* w3c; uint4* act1b; uint4* act2b;
+};
+
+__device__ __forceinline__ float wave32_max(float v) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave32_sum(float v) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+
+// bf16 compute mode hands dL/dlogits to the backward MFMAs as bf16: round once here (RNE), keep the fp32 container
+template <bool DYBF16>
+__device__ __forceinline__ float dy_round(float x) {
+    if (!DYBF16) return x;
+    return (float)(__bf16)x;
+}
+
+// l[ts][i]: logit of action 128*ts + 4*j + i of the state, present in both lane halves (j = lane & 31).
+template <int MODE, int TPS, bool DYBF16>
+__device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t state, const int64_t sid, const uint32_t act,
+                                            float (&l)[TPS][4], const int lane, const int j, const int h) {
+    constexpr int A = 128 * TPS;
+    // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
+    bool on[TPS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int ts = 0; ts < TPS; ++ts) {
+        on[ts] = (act >> (8 * ts + (j >> 2))) & 1u;
+        if (on[ts]) m = fmaxf(m, fmaxf(fmaxf(l[ts][0], l[ts][1]), fmaxf(l[ts][2], l[ts][3])));
+    }
+    m = wave32_max(m);
+    float p[TPS][4];
+    float ssum = 0.0f;
+#pragma unroll
+    for (int ts = 0; ts < TPS; ++ts) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[ts][i] = on[ts] ? exp_dev(l[ts][i] - m) : 0.0f;
+        const float st = ((p[ts][0] + p[ts][1]) + p[ts][2]) + p[ts][3];
+        ssum = (ts == 0) ? st : ssum + st;                 // tile partials in tile order, then the butterfly
+    }
+    ssum = wave32_sum(ssum);
+#pragma unroll
+    for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[ts][i] = p[ts][i] / ssum;
+
+    if (MODE == 0) {
+        if (h == 0) {
+#pragma unroll
+            for (int ts = 0; ts < TPS; ++ts)
+                reinterpret_cast<float4*>(a.probs_out)[((size_t)state * TPS + ts) * 32 + j] =
+                    make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
+        }
+    }
+    if (MODE == 1) {
+        // rand(Categorical(p)): sequential fp32 inverse-CDF walk, same uniform as the oracle
+        uint32_t rnd[4];
+        philox4x32_10((uint32_t)(a.global_offset + state), a.tick[state], 0u, 0u, a.k0, a.k1, rnd);
+        const float u = u01_from_u32(rnd[0]);
+        float cp = readlane_f(p[0][0], 0);
+        int ia = 0;
+#pragma unroll
+        for (int q = 1; q < A; ++q) {
+            const float pa = readlane_f(p[q >> 7][q & 3], (q & 127) >> 2);
+            const bool take = cp <= u;
+            cp = take ? cp + pa : cp;
+            ia = take ? q : ia;
+        }
+        float cand = 0.0f;
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cand = ((ia >> 7) == ts && (ia & 3) == i) ? p[ts][i] : cand;
+        const float psel = __shfl(cand, (ia & 127) >> 2);
+        if (lane == 0) {
+            if (!(psel > 0.0f)) atomicOr(a.err, 8);     // @assert ap[a] > 0.0
+            a.actions_out[state] = ia;
+            a.psel_out[state] = psel;
+        }
+        if (a.full_probs && h == 0) {
+#pragma unroll
+            for (int ts = 0; ts < TPS; ++ts)
+                reinterpret_cast<float4*>(a.full_probs)[((size_t)state * TPS + ts) * 32 + j] =
+                    make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
+        }
+    }
+    if (MODE == 2) {
+        const int ab = a.actions[sid];
+        const float po = a.p_old[sid];
+        const float adv = a.adv[sid];
+        float cand = 0.0f;
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cand = ((ab >> 7) == ts && (ab & 3) == i) ? p[ts][i] : cand;
+        const float ps = __shfl(cand, (ab & 127) >> 2);
+        const float gain = ps / po * adv;                                    // src/train.jl:39 (Float32)
+        const double clip = adv >= 0.0f ? (1.0 + a.eps) * (double)adv : (1.0 - a.eps) * (double)adv;   // :1-7
+        const bool unclipped = (double)gain < clip;
+        const double minval = unclipped ? (double)gain : clip;
+        const float sA = 1e-8f / (float)A;                                   // smooth/size(probs,1)  :22
+        float lg[TPS][4], hl = 0.0f;
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float sp = p[ts][i] + sA; lg[ts][i] = logf(sp); hl += sp * lg[ts][i]; }
+        hl = wave32_sum(hl);
+        float dp[TPS][4], dot = 0.0f;
+        const float dsel = unclipped ? -(a.inv_B * adv / po) : 0.0f;
+#pragma unroll
+        for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dp[ts][i] = a.c_over_B * (lg[ts][i] + 1.0f) + ((128 * ts + 4 * j + i == ab) ? dsel : 0.0f);
+                dot += p[ts][i] * dp[ts][i];
+            }
+        dot = wave32_sum(dot);
+        if (h == 0) {
+#pragma unroll
+            for (int ts = 0; ts < TPS; ++ts)
+                a.dY[((size_t)state * TPS + ts) * 32 + j] =
+                    make_float4(dy_round<DYBF16>(p[ts][0] * (dp[ts][0] - dot)), dy_round<DYBF16>(p[ts][1] * (dp[ts][1] - dot)),
+                                dy_round<DYBF16>(p[ts][2] * (dp[ts][2] - dot)), dy_round<DYBF16>(p[ts][3] * (dp[ts][3] - dot)));
+        }
+        if (lane == 0) { a.loss_terms[state * 2] = minval; a.loss_terms[state * 2 + 1] = (double)(-hl); }
+    }
+}
