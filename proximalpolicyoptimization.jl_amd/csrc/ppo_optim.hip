@@ -23,27 +23,35 @@ static ParamLayout layout_of(const ppo_policy_s* p) {
 __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
                                   float* __restrict__ grad_tail);
 
-__global__ void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg, ParamLayout L,
-                              float* __restrict__ grad, const double* __restrict__ terms, int64_t B, double inv_Bg,
-                              double entropy_weight) {
+// Block = 64 consecutive slab elements x 4 slab groups (wave g sums slabs g, g+4, g+8, ... with 8 loads in flight);
+// the four partial sums meet in LDS and are added in a fixed order.  4x the waves of a one-thread-per-element
+// layout: the 87 MB slab walk needs the memory-level parallelism (341 blocks of one wave per SIMD did 3.3 TB/s).
+__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg, ParamLayout L,
+                                                     float* __restrict__ grad, const double* __restrict__ terms, int64_t B,
+                                                     double inv_Bg, double entropy_weight) {
     if (blockIdx.x == gridDim.x - 1) {          // the extra last block reduces the per-sample loss terms
         loss_reduce_block(terms, B, inv_Bg, entropy_weight, grad + L.np);
         return;
     }
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + el;
     const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
     const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
-    if (e >= total) return;
-    // fixed summation order (8 interleaved partial sums, then a fixed tree): deterministic, and the 8
-    // independent loads in flight hide the HBM latency of the slab walk
+    // fixed summation order: 8 interleaved partial sums per slab group, a fixed tree, then the 4 groups in order
     float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int g = 0;
-    for (; g + 8 <= nwg; g += 8) {
+    if (e < total) {
+        int g = grp;
+        for (; g + 28 < nwg; g += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ps[u] += slabs[(size_t)(g + u) * slab_stride + e];
+            for (int u = 0; u < 8; ++u) ps[u] += slabs[(size_t)(g + 4 * u) * slab_stride + e];
+        }
+        for (int u = 0; g < nwg; g += 4, ++u) ps[u] += slabs[(size_t)g * slab_stride + e];
     }
-    for (int u = 0; g < nwg; ++g, ++u) ps[u] += slabs[(size_t)g * slab_stride + e];
-    const float s = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    part[grp][el] = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+    __syncthreads();
+    if (grp != 0 || e >= total) return;
+    const float s = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
     int64_t canon = -1;
     if (e < nW2) {
         const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
@@ -207,7 +215,7 @@ int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double 
     ParamLayout L = layout_of(p);
     const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     ProfScope ps("k_grad_reduce");
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 255) / 256) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 63) / 64) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
                        slab_floats(p->F, p->HID), p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
                        entropy_weight);
     HIP_TRY(hipGetLastError());

@@ -44,6 +44,9 @@ __device__ __forceinline__ void pack_tile(const f32x16& acc, uint4 (&out)[2]) {
     out[0] = make_uint4(pack_bf16(acc[0], acc[1]), pack_bf16(acc[2], acc[3]), pack_bf16(acc[4], acc[5]), pack_bf16(acc[6], acc[7]));
     out[1] = make_uint4(pack_bf16(acc[8], acc[9]), pack_bf16(acc[10], acc[11]), pack_bf16(acc[12], acc[13]), pack_bf16(acc[14], acc[15]));
 }
+// leakyrelu'(h) for the two bf16 values of a packed dword: h > 0 <=> the bit pattern read as int16 is > 0
+__device__ __forceinline__ float slope_lo(uint32_t d) { return (int16_t)(d & 0xFFFFu) > 0 ? 1.0f : 0.01f; }
+__device__ __forceinline__ float slope_hi(uint32_t d) { return (int32_t)d >= 0x10000 ? 1.0f : 0.01f; }
 __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // ================================================================ forward
@@ -216,11 +219,18 @@ int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& a, int mode, int64_t B,
 struct BwdBArgs {
     const int8_t* states; const int32_t* idx; int32_t B;   // B = number of 32-row tiles (states * tps), < 2^31
     int tps_shift;                                          // tiles per state = 1 << tps_shift (H = 32 or 128)
+    int nwg;                                                // == gridDim.x (as an argument: no dispatch-packet reload in the loop)
     const uint4* act1b; const uint4* act2b; const float4* dY;
     const uint4* w2tb; const uint2* w3tb;
     uint4* z1f; uint4* xf;                                  // operand fragments handed to k_policy_dw1_bf16
     float* slabs; size_t slab_stride;
+    unsigned long long* stamps;                             // diagnostic build only (-DPPO_BF16_STAMP)
 };
+#ifdef PPO_BF16_STAMP
+#define BSTAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define BSTAMP(i) do {} while (0)
+#endif
 
 // The weight-gradient accumulators decide the shape of the backward pass: dW2 (HID x HID) and dW1 (HID x F) need
 // 22 accumulator tiles = 352 registers per SIMD for HID = 256 -- two waves per SIMD cannot hold both next to their
@@ -241,8 +251,18 @@ struct BwdB {
     static_assert((STX / 4) % 64 == 16 || (STX / 4) % 64 == 48, "X image stride");
     static constexpr int IMG = 32 * ST;
     static constexpr int oZ2 = 0, oH1 = IMG, oZ1 = 2 * IMG, oH2 = 3 * IMG, oZF = 4 * IMG, oX = oZF + NS * 1024,
-                         oDY = oX + 32 * STX, total = oDY + 512;
+                         oDY = oX + 32 * STX, oW = oDY + 512, total = oW + NT * (NS / 2) * 1024;
+    static_assert(total <= 160 * 1024, "LDS budget");
 };
+
+// global accesses as wave-uniform base (SGPR pair) + 32-bit per-lane byte offset: saddr-form instructions, no per-lane
+// 64-bit pointers (sixteen of those for the W2^T ring alone would spill, and hipcc waits vmcnt(0) at every reload)
+__device__ __forceinline__ uint4 ldg16(const void* sbase, unsigned voff) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + voff);
+}
+__device__ __forceinline__ void stg16(void* sbase, unsigned voff, const uint4& v) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(sbase) + voff) = v;
+}
 
 // two transposed 4x16 block reads -> one 32x32x16 operand fragment (8 consecutive rows of the lane's column)
 __device__ __forceinline__ uint4 tr_frag(const char* p0, const char* p1) {
@@ -269,8 +289,19 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     uint4* const sZF = reinterpret_cast<uint4*>(smem_c + C::oZF);
     char* const imgX = smem_c + C::oX;
     float* const sDY = reinterpret_cast<float*>(smem_c + C::oDY);
+    uint4* const sW = reinterpret_cast<uint4*>(smem_c + C::oW);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // the first half (k-steps 0 .. NS/2-1) of this wave's W2^T fragments stays in LDS for the whole launch (HID^2 bytes:
+    // all that is left of the 160 KiB next to the images); the second half streams from L2 once per tile and is
+    // issued at the top of the tile, so the dH1 chain of phase B never waits for a refill
+    constexpr int NSH = NS / 2;
+#pragma unroll
+    for (int i = 0; i < FT; ++i)
+#pragma unroll
+        for (int s = 0; s < NSH; ++s)
+            sW[((w * FT + i) * NSH + s) * 64 + lane] = a.w2tb[((size_t)(w * FT + i) * NS + s) * 64 + lane];
 
     // zero the padded X image once (columns >= F are never written afterwards)
     for (int i = tid; i < 32 * STX / 4; i += NTHR) reinterpret_cast<uint32_t*>(imgX)[i] = 0u;
@@ -282,7 +313,8 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accW2[i][kt][r] = 0.0f;
-    float db1[FT], db2[FT], dw3[FT][4], db3 = 0.f;
+    float db1[FT], db2[FT], dw3[FT][4];
+    float4 db3 = make_float4(0.f, 0.f, 0.f, 0.f);        // per-row partial sums of dY (combined over the 32 rows at the end)
 #pragma unroll
     for (int i = 0; i < FT; ++i) { db1[i] = db2[i] = 0.f; dw3[i][0] = dw3[i][1] = dw3[i][2] = dw3[i][3] = 0.f; }
 
@@ -314,41 +346,73 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     uint4 nh2[FT][2], nh1[FT][2];
     float4 ndy;
     uint32_t nx[XPD];
-    auto prefetch = [&](int t) {
-        const int sidx = __builtin_amdgcn_readfirstlane(a.idx[t >> a.tps_shift]);
+    int xoff[XPD];                                          // X-image byte offset of state dword tid + i*256 (tile-independent)
+#pragma unroll
+    for (int i = 0; i < XPD; ++i) {
+        const int d = tid + i * NTHR;
+        xoff[i] = (d < XDW) ? (d / (F / 4)) * STX + (d % (F / 4)) * 8 : -1;
+    }
+    unsigned lo16 = (unsigned)lane * 16u;
+    // sidx: transition id of tile t's state.  It is itself a global load, so it is fetched one tile earlier still
+    // (idx_next below): a prefetch that first had to wait for its own index stalled phase B for an HBM round trip.
+    auto prefetch = [&](int t, int sidx_v) {
+        const int sidx = __builtin_amdgcn_readfirstlane(sidx_v);
 #pragma unroll
         for (int i = 0; i < FT; ++i) {
-            const size_t base = ((size_t)t * NT + (w * FT + i)) * 128 + lane;
-            nh2[i][0] = a.act2b[base]; nh2[i][1] = a.act2b[base + 64];
-            nh1[i][0] = a.act1b[base]; nh1[i][1] = a.act1b[base + 64];
+            const size_t base = ((size_t)t * NT + (w * FT + i)) * 128;          // wave-uniform
+            nh2[i][0] = ldg16(a.act2b + base, lo16); nh2[i][1] = ldg16(a.act2b + base + 64, lo16);
+            nh1[i][0] = ldg16(a.act1b + base, lo16); nh1[i][1] = ldg16(a.act1b + base + 64, lo16);
         }
-        ndy = a.dY[(size_t)t * 32 + j];
-        const uint32_t* xs = reinterpret_cast<const uint32_t*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
+        ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+        const char* xs = reinterpret_cast<const char*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const int d = tid + i * NTHR;
-            nx[i] = d < XDW ? xs[d] : 0u;
+            const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
+            nx[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
         }
     };
-    if ((int)blockIdx.x < a.B) prefetch((int)blockIdx.x);
+    auto tile_or_last = [&](int t) { return t < a.B ? t : a.B - 1; };
+    int idx_next = 0;
+    if ((int)blockIdx.x < a.B) {
+        prefetch((int)blockIdx.x, a.idx[(int)blockIdx.x >> a.tps_shift]);
+        idx_next = a.idx[tile_or_last((int)blockIdx.x + a.nwg) >> a.tps_shift];
+    }
     __syncthreads();
 
-    for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+#ifdef PPO_BF16_STAMP
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
+    for (int tile = blockIdx.x; tile < a.B; tile += a.nwg) {
         // ================= phase A: dZ2 = (W3^T dY) . lrelu'(H2), images (inputs were fetched one tile ahead)
+#ifdef PPO_BF16_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BSTAMP(0);
+#endif
+        // per-tile opaque lane offset: every global address below is re-formed from it (SGPR base + this VGPR) instead
+        // of being hoisted out of the tile loop as ~30 loop-invariant 64-bit per-lane pointers that then spill
+        asm volatile("" : "+v"(lo16));
         const float4 dy = ndy;
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const int d = tid + i * NTHR;
-            if (d < XDW) {
+            if (xoff[i] >= 0) {
                 const uint32_t v = nx[i];
-                const int row = d / (F / 4), c4 = d % (F / 4);
-                *reinterpret_cast<uint2*>(imgX + row * STX + c4 * 8) =
+                *reinterpret_cast<uint2*>(imgX + xoff[i]) =
                     make_uint2(pack_bf16((float)(int)(int8_t)(v), (float)(int)(int8_t)(v >> 8)),
                                pack_bf16((float)(int)(int8_t)(v >> 16), (float)(int)(int8_t)(v >> 24)));
             }
         }
+        // second half of this wave's W2^T fragments (L2-resident): issued at the top of the tile, right behind the wait
+        // for the prefetched inputs, so they land under phase A (sched_barrier: hipcc otherwise sinks them to the barrier)
+        uint4 ring[NSH][FT];
+        const uint4* wt = a.w2tb + (size_t)(w * FT) * NS * 64;       // wave-uniform base of this wave's W2^T tiles
+#pragma unroll
+        for (int g = 0; g < NSH; ++g)
+#pragma unroll
+            for (int i = 0; i < FT; ++i) ring[g][i] = ldg16(wt + (size_t)(i * NS + NSH + g) * 64, lo16);
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
+        db3.x += dy.x; db3.y += dy.y; db3.z += dy.z; db3.w += dy.w;
         const uint4 bdy = (h == 0) ? make_uint4(dy01, dy23, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int i = 0; i < FT; ++i) {
@@ -360,8 +424,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t d = dw(nh2[i][r >> 3], (r >> 1) & 3);
-                const float hv = (r & 1) ? bf16_hi(d) : bf16_lo(d);
-                acc[r] = acc[r] * (hv > 0.0f ? 1.0f : 0.01f);
+                acc[r] = acc[r] * ((r & 1) ? slope_hi(d) : slope_lo(d));
             }
             uint4 zf[2];
             pack_tile(acc, zf);
@@ -375,36 +438,51 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[i][g >> 1], 2 * (g & 1)), dw(nh1[i][g >> 1], 2 * (g & 1) + 1));
             }
         }
-        // first W2^T fragments of phase B (L2-resident, independent of the barrier): issued now so they land under it
-        constexpr int PFB = 4;                                       // k-steps in flight (FT fragments each)
-        uint4 ring[PFB][FT];
-        const uint4* wt = a.w2tb + (size_t)(w * FT) * NS * 64 + lane;
-#pragma unroll
-        for (int g = 0; g < PFB; ++g)
-#pragma unroll
-            for (int i = 0; i < FT; ++i) ring[g][i] = wt[(size_t)(i * NS + g) * 64];
+        BSTAMP(1);
         __syncthreads();
+        BSTAMP(2);
         // ================= phase B: dH1^T[k-tiles of this wave] = W2^T dZ2^T, dZ1 = dH1 . lrelu'(H1) -> image
         {
-            // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A) and
-            // land under the MFMAs of phases B and C
-            const int ntile = (tile + (int)gridDim.x < a.B) ? tile + (int)gridDim.x : tile;     // harmless re-load on the last tile
-            prefetch(ntile);
+            // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A).  They
+            // are issued BEHIND the streamed W2^T half: vmcnt retires in order, so the chain below waits only for
+            // fragments that are older than these loads
+            prefetch(tile_or_last(tile + a.nwg), idx_next);   // harmless re-load behind the last tile
+            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
             f32x16 acc[FT];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            // The k-steps whose W2^T fragments were streamed into registers run first (their registers free up), then
+            // the LDS-resident ones.  LDS operands are read DL steps ahead of their MFMAs (explicit queue; sched_barrier
+            // pins the order): one step ahead covers 64 cycles of MFMA, a ds_read_b128 round trip is longer than that.
+            constexpr int DL = 3;
+            uint4 bzq[DL], wlq[DL][FT];
+            auto kstep = [&](int t) { return t < NSH ? t + NSH : t - NSH; };
+            auto issue = [&](int t) {
+                const int s = kstep(t);
+                bzq[t % DL] = sZF[s * 64 + lane];
+                if (s < NSH) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint4 bz = sZF[s * 64 + lane];
-#pragma unroll
-                for (int i = 0; i < FT; ++i) {
-                    const uint4 wv = ring[s % PFB][i];
-                    if (s + PFB < NS) ring[s % PFB][i] = wt[(size_t)(i * NS + s + PFB) * 64];
-                    acc[i] = mfma_bf16(wv, bz, acc[i]);
+                    for (int i = 0; i < FT; ++i) wlq[t % DL][i] = sW[((w * FT + i) * NSH + s) * 64 + lane];
                 }
+            };
+#pragma unroll
+            for (int t = 0; t < DL; ++t) issue(t);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int s = kstep(t);
+                const uint4 bz = bzq[t % DL];
+                uint4 wv[FT];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) wv[i] = (s < NSH) ? wlq[t % DL][i] : ring[s - NSH][i];
+                if (t + DL < NS) issue(t + DL);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < FT; ++i) acc[i] = mfma_bf16(wv[i], bz, acc[i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            BSTAMP(3);
 #pragma unroll
             for (int i = 0; i < FT; ++i) {
                 const int ft = w * FT + i;
@@ -414,8 +492,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t d = (r & 2) ? hc[r >> 2].y : hc[r >> 2].x;
-                    const float hv = (r & 1) ? bf16_hi(d) : bf16_lo(d);
-                    acc[i][r] = acc[i][r] * (hv > 0.0f ? 1.0f : 0.01f);
+                    acc[i][r] = acc[i][r] * ((r & 1) ? slope_hi(d) : slope_lo(d));
                 }
                 uint4 z1[2];
                 pack_tile(acc[i], z1);
@@ -430,8 +507,12 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         // Phase C writes no LDS, so the other waves' phase-B reads need no barrier here; the one at the end of the
         // tile keeps the next phase A from overwriting the images early.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BSTAMP(4);
         // ================= phase C: products that contract over the 32 rows (operands: transposed image reads)
         {
+            // (interleaving these MFMAs with the dH1 chain to hide its W2^T refills was measured slower: the chain's
+            // two working accumulators then compete with the 256 resident ones for the AGPR half and hipcc parks two
+            // dW2 tiles in scratch)
             uint4 az[FT][2];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -450,6 +531,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
             }
+            BSTAMP(5);
             // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
             // MFMA tile that would be 7/8 zero padding): lane (f, h) holds rows 16s + 8h + e of column f
 #pragma unroll
@@ -466,6 +548,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                         dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
                     }
                 }
+            BSTAMP(6);
             // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
             // for k_policy_dw1_bf16
 #pragma unroll
@@ -474,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 for (int s = 0; s < 2; ++s) {
                     const uint4 z = tr_frag(imgZ1 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ1 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
                     db1[i] += sum_frag(z);
-                    a.z1f[(((size_t)tile * NT + (w * FT + i)) * 2 + s) * 64 + lane] = z;
+                    stg16(a.z1f + (((size_t)tile * NT + (w * FT + i)) * 2 + s) * 64, lo16, z);
                 }
 #pragma unroll
             for (int i = 0; i < FT; ++i) {
@@ -482,18 +565,18 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 if (it < NI) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        a.xf[(((size_t)tile * NI + it) * 2 + s) * 64 + lane] =
-                            tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it);
+                        stg16(a.xf + (((size_t)tile * NI + it) * 2 + s) * 64, lo16,
+                              tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it));
                 }
-            }
-            if (tid < 4) {
-                float s = 0.f;
-                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
-                db3 += s;
             }
         }
         __syncthreads();
+        BSTAMP(7);
     }
+#ifdef PPO_BF16_STAMP
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = st_sum[i];
+#endif
 
     // ================= slab (same fragment order as the fp32 kernel: k_grad_reduce maps it to Flux order);
     // the dW1 region is written by k_policy_dw1_bf16
@@ -521,7 +604,15 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(d3[0], d3[1], d3[2], d3[3]);
         }
     }
-    if (tid < 4) sb3[tid] = db3;
+    if (w == 0) {
+        float t4[4] = {db3.x, db3.y, db3.z, db3.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) t4[o] += __shfl_xor(t4[o], off);
+        }
+        if (lane == 0) { sb3[0] = t4[0]; sb3[1] = t4[1]; sb3[2] = t4[2]; sb3[3] = t4[3]; }
+    }
 }
 
 // dW1[k][i] += sum_rows dZ1[k][row] X[row][i] from the operand fragments of k_policy_bwd_bf16.  Same tile -> workgroup
@@ -537,18 +628,31 @@ __global__ __launch_bounds__(HID * 2) void k_policy_dw1_bf16(BwdBArgs a) {
     for (int it = 0; it < NI; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[it][r] = 0.0f;
+    // next tile's fragments are fetched while the current tile's MFMAs run (two waves per SIMD, HBM/MALL-bound)
+    const unsigned lo16 = (unsigned)lane * 16u;
+    uint4 z[2], x[NI][2];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) z[s] = ldg16(a.z1f + (((size_t)t * NT + w) * 2 + s) * 64, lo16);
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) x[it][s] = ldg16(a.xf + (((size_t)t * NI + it) * 2 + s) * 64, lo16);
+    };
+    if ((int)blockIdx.x < a.B) fetch((int)blockIdx.x);
     for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
-        uint4 z[2], x[NI][2];
+        uint4 cz[2], cx[NI][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) z[s] = a.z1f[(((size_t)tile * NT + w) * 2 + s) * 64 + lane];
-#pragma unroll
-        for (int it = 0; it < NI; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) x[it][s] = a.xf[(((size_t)tile * NI + it) * 2 + s) * 64 + lane];
+        for (int s = 0; s < 2; ++s) cz[s] = z[s];
 #pragma unroll
         for (int it = 0; it < NI; ++it)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc[it] = mfma_bf16(z[s], x[it][s], acc[it]);
+            for (int s = 0; s < 2; ++s) cx[it][s] = x[it][s];
+        fetch((tile + (int)gridDim.x < a.B) ? tile + (int)gridDim.x : tile);      // harmless re-load on the last tile
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[it] = mfma_bf16(cz[s], cx[it][s], acc[it]);
     }
     float* sW1 = a.slabs + (size_t)blockIdx.x * a.slab_stride + (size_t)HID * HID;
 #pragma unroll
@@ -556,6 +660,15 @@ __global__ __launch_bounds__(HID * 2) void k_policy_dw1_bf16(BwdBArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = acc[it][r];
 }
+
+#ifdef PPO_BF16_STAMP
+static unsigned long long* g_bf16_stamps = nullptr;
+extern "C" int32_t ppo_debug_bf16_stamps(unsigned long long* out) {
+    if (!g_bf16_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_bf16_stamps, 256 * 4 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
     BwdBArgs a;
@@ -570,8 +683,14 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     a.z1f = (uint4*)p->act1.p + (size_t)a.B * (p->HID / 32) * 128;
     a.xf = (uint4*)p->act2.p + (size_t)a.B * (p->HID / 32) * 128;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    a.stamps = nullptr;
+#ifdef PPO_BF16_STAMP
+    if (!g_bf16_stamps) (void)hipMalloc((void**)&g_bf16_stamps, 256 * 4 * 8 * 8);
+    a.stamps = g_bf16_stamps;
+#endif
     const int nwg = (int)(a.B < 256 ? a.B : 256);
     p->nwg_bwd = nwg;
+    a.nwg = nwg;
 #define LAUNCHB(FF, HH)                                                                                           \
     do {                                                                                                          \
         static_assert(BwdB<FF, HH>::NI <= BwdB<FF, HH>::NT, "X fragments are emitted by waves 0..NI-1");          \
