@@ -44,8 +44,8 @@ typedef struct ppo_rollouts_s* ppo_rollouts_t;
 
 /* advantage plugin modes (batch_advantage, src/ProximalPolicyOptimization.jl:29; no
  * implementation exists in the reference, old scripts use raw returns) */
-#define PPO_ADV_RETURNS 0
-#define PPO_ADV_RETURNS_NORMALISED 1
+#define PPO_ADV_RETURNS 0            /* advantage = returns (what the reference's old scripts do)            */
+#define PPO_ADV_RETURNS_NORMALISED 1 /* (R - mean) / (std + 1e-8) over the minibatch (population std, fp64 stats) */
 
 /* ---------------------------------------------------------------- library / device */
 int32_t ppo_version(void);

@@ -33,6 +33,7 @@ import shutil
 import numpy as np
 
 from . import _lib
+from . import checkpoint  # noqa: F401
 from ._lib import PPOError, call, lib
 from .disk import (DiskDataset, DiskRollouts, bson_decode_state, bson_encode_state, export_reference_layout,  # noqa: F401
                    update_, write_returns_to_disk)
@@ -667,7 +668,18 @@ def load_disk_rollouts(state_data_dir, env):
 
 
 # ------------------------------------------------------------------ training
-def step_batch_(policy, optimizer, dataset, batch_indices, epsilon, entropy_weight):
+ADVANTAGE_MODES = {"returns": 0, "returns_normalised": 1}
+
+
+def _adv_mode(advantage):
+    """batch_advantage plugin (src/ProximalPolicyOptimization.jl:29; no implementation in the reference): "returns"
+    (identity, what the reference's scripts do) or "returns_normalised" ((R - mean) / (std + 1e-8) per minibatch)."""
+    if advantage not in ADVANTAGE_MODES:
+        raise PPOError(-1, "AssertionError: advantage must be one of %s" % sorted(ADVANTAGE_MODES))
+    return ADVANTAGE_MODES[advantage]
+
+
+def step_batch_(policy, optimizer, dataset, batch_indices, epsilon, entropy_weight, advantage="returns"):
     """One optimiser step on dataset[batch_indices] (1-based): gather + batch_advantage (=returns) +
     get_linear_action_index + step_batch! (src/train.jl:98-120, 54-84).  Returns (ppoloss, entropy_weight*entropyloss)."""
     adam = optimizer._adam()
@@ -675,22 +687,22 @@ def step_batch_(policy, optimizer, dataset, batch_indices, epsilon, entropy_weig
     ii = np.ascontiguousarray(np.asarray(batch_indices, np.int64) - 1)
     a, b = C.c_double(0), C.c_double(0)
     call("ppo_step_batch", policy._h, oh, dataset.rollouts._h, _p(ii, _lib.c_i64p), ii.size, float(epsilon),
-         float(entropy_weight), 0, C.byref(a), C.byref(b))
+         float(entropy_weight), _adv_mode(advantage), C.byref(a), C.byref(b))
     return a.value, b.value
 
 
-def forward_backward(policy, dataset, batch_indices, epsilon, entropy_weight, B_global=None):
+def forward_backward(policy, dataset, batch_indices, epsilon, entropy_weight, B_global=None, advantage="returns"):
     """Gradient only (no update): leaves the flat gradient in policy.grad(); returns the two losses."""
     ii = np.ascontiguousarray(np.asarray(batch_indices, np.int64) - 1)
     call("ppo_forward_backward", policy._h, dataset.rollouts._h, _p(ii, _lib.c_i64p), ii.size,
-         int(B_global or ii.size), float(epsilon), float(entropy_weight), 0)
+         int(B_global or ii.size), float(epsilon), float(entropy_weight), _adv_mode(advantage))
     a, b = C.c_double(0), C.c_double(0)
     call("ppo_last_losses", policy._h, C.byref(a), C.byref(b))
     return a.value, b.value
 
 
 def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight, perm=None, seed=0,
-               parallel=None, verbose=True):
+               parallel=None, verbose=True, advantage="returns"):
     """PPO.ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight)
     (src/train.jl:130-153) -> (ppo_loss_history, entropy_loss_history, lr_history).
     perm: optional [num_epochs, len] 1-based permutations standing in for randperm (:93)."""
@@ -709,7 +721,8 @@ def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entr
         keep = parallel.make_hook(policy)
         fn = keep
     call("ppo_train", policy._h, oh, dataset.rollouts._h, float(epsilon), int(batch_size), int(num_epochs),
-         float(entropy_weight), 0, _p(pp, _lib.c_i64p) if pp is not None else None, int(seed), int(world), fn, None,
+         float(entropy_weight), _adv_mode(advantage), _p(pp, _lib.c_i64p) if pp is not None else None, int(seed),
+         int(world), fn, None,
          _p(ph, _lib.c_f64p), _p(eh, _lib.c_f64p), _p(lh, _lib.c_f64p))
     lr = get_optimizer_learning_rate(optimizer)
     if verbose:
@@ -804,3 +817,15 @@ class DataParallel:
             except Exception:
                 return 1
         return _lib.ALLREDUCE_FN(hook)
+
+
+# ---------------------------------------------------------------- checkpoints (BSON.@save / BSON.@load of the policy)
+def save_policy(path, policy):
+    """BSON.@save path policy (examples/triangle/distance_weighted/triangle_utilities.jl:370-373): the document
+    BSON.jl writes for SimplePolicy.Policy, readable by the reference."""
+    checkpoint.save_policy(path, policy)
+
+
+def load_policy(path, seed=0, dtype="f32"):
+    """BSON.@load path policy -> HipPolicy holding the saved Float32 weights (e.g. the reference's test/output/*.bson)."""
+    return checkpoint.load_policy(path, HipPolicy, seed=seed, dtype=dtype)

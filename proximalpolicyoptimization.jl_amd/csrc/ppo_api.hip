@@ -634,9 +634,15 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
 
 // idx_dev: transition ids (already resolved through the dataset index)
 static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
-                                    int64_t B_global, double eps, double ew) {
+                                    int64_t B_global, double eps, double ew, int32_t adv_mode) {
     PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
-    PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew));
+    const float* adv = ro->returns.p;                       // batch_advantage = returns (reference-equivalent)
+    if (adv_mode == PPO_ADV_RETURNS_NORMALISED) {           // normalised over this rank's minibatch
+        PPO_TRY(pol->adv_col.alloc((size_t)ro->capT * ro->N));
+        PPO_TRY(launch_adv_normalise(ro->returns.p, idx_dev, B, pol->adv_col.p));
+        adv = pol->adv_col.p;
+    }
+    PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew, adv));
     PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
     PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
     pol->last_B = B; pol->last_entropy_weight = ew;
@@ -658,7 +664,7 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
     ARG_CHECK(B >= 1 && B <= ro->len, "step_batch!: 1 <= batch_size <= num_data (src/train.jl:88)");
     ARG_CHECK(B_global >= B, "step_batch!: B_global < B");
     ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "step_batch!: shape mismatch");
-    if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
+    if (adv_mode != PPO_ADV_RETURNS && adv_mode != PPO_ADV_RETURNS_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
     for (int64_t i = 0; i < B; ++i) ARG_CHECK(sample_idx[i] >= 0 && sample_idx[i] < ro->len, "dataset index out of range (src/rollout_buffer.jl:105-106)");
     PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
     DevBuf<int64_t> pos;
@@ -667,7 +673,7 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
     hipLaunchKernelGGL(k_gather_index, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, g_stream, ro->index.p, pos.p, B,
                        ro->len, pol->idx.p, pol->err.p);
     HIP_TRY(hipGetLastError());
-    PPO_TRY(forward_backward_dev(pol, ro, pol->idx.p, B, B_global, epsilon, entropy_weight));
+    PPO_TRY(forward_backward_dev(pol, ro, pol->idx.p, B, B_global, epsilon, entropy_weight, adv_mode));
     HIP_TRY(hipStreamSynchronize(g_stream));
     return PPO_OK;
 }
@@ -712,7 +718,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
     ARG_CHECK(num_epochs >= 0 && world >= 1, "ppo_train!: bad epochs/world");
     ARG_CHECK(world == 1 || allreduce, "ppo_train!: world > 1 needs an all-reduce hook");
     ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "ppo_train!: shape mismatch");
-    if (adv_mode != PPO_ADV_RETURNS) { ppo_set_error("batch_advantage: only PPO_ADV_RETURNS is implemented"); return PPO_ERR_UNSUPPORTED; }
+    if (adv_mode != PPO_ADV_RETURNS && adv_mode != PPO_ADV_RETURNS_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
     PPO_TRY(train_reserve(pol, batch_size * (ro->H / 32)));
     const int64_t nb = (len + batch_size - 1) / batch_size;
     DevBuf<int32_t> order; DevBuf<int64_t> permd; DevBuf<float> hist;
@@ -734,7 +740,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
         int64_t b = 0;
         for (int64_t start = 0; start < len; start += batch_size, ++b) {           // :95-96 (last batch may be short)
             const int64_t B = (start + batch_size <= len) ? batch_size : (len - start);
-            PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, B * world, epsilon, entropy_weight));
+            PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, B * world, epsilon, entropy_weight, adv_mode));
             if (allreduce) {                     // every rank of a data-parallel run; a world of 1 may pass it too
                 const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
                 if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }

@@ -90,6 +90,7 @@ struct ppo_policy_s {
     DevBuf<double> loss_terms;         // [tiles][2]
     DevBuf<float> slabs;               // [nwg][slab]
     DevBuf<int32_t> idx;               // gathered transition ids of the minibatch
+    DevBuf<float> adv_col;             // batch_advantage scratch column [T*N] (PPO_ADV_RETURNS_NORMALISED)
     DevBuf<int32_t> err;               // device error flag
     int64_t cap_tiles = 0;
     int32_t nwg_bwd = 0;
@@ -154,8 +155,10 @@ int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uin
                             int32_t H, float* probs_dev);
 int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
                               int32_t* actions_out, float* psel_out, float* full_probs_or_null);
+// adv_col: the advantage column indexed by transition id (ro->returns for PPO_ADV_RETURNS)
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
-                                int64_t B_global, double eps, double entropy_weight);
+                                int64_t B_global, double eps, double entropy_weight, const float* adv_col);
+int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col);
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 // bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
 struct FwdArgs;

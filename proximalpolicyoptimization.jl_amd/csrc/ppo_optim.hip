@@ -242,3 +242,38 @@ int32_t launch_feistel_index(const int32_t* index_dev, int64_t len, uint64_t see
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }
+
+// batch_advantage plugin, PPO_ADV_RETURNS_NORMALISED (src/ProximalPolicyOptimization.jl:29 declares the plugin, the
+// reference ships no implementation): adv = (R - mean(R)) / (std(R) + 1e-8) over the minibatch, population std,
+// statistics in fp64.  One workgroup: two fixed-order block reductions, then the normalised values are scattered
+// into a scratch column at their transition ids so the forward kernel reads them exactly like the returns column.
+__global__ __launch_bounds__(1024) void k_adv_normalise(const float* __restrict__ returns, const int32_t* __restrict__ idx,
+                                                        int64_t B, float* __restrict__ adv_col) {
+    __shared__ double red[1024];
+    __shared__ double stat[2];
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = t; i < B; i += 1024) s += (double)returns[idx[i]];
+    red[t] = s;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+    if (t == 0) stat[0] = red[0] / (double)B;
+    __syncthreads();
+    const double mean = stat[0];
+    s = 0.0;
+    for (int64_t i = t; i < B; i += 1024) { const double d = (double)returns[idx[i]] - mean; s += d * d; }
+    __syncthreads();
+    red[t] = s;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+    if (t == 0) stat[1] = 1.0 / (sqrt(red[0] / (double)B) + 1e-8);
+    __syncthreads();
+    const double inv = stat[1];
+    for (int64_t i = t; i < B; i += 1024) { const int32_t k = idx[i]; adv_col[k] = (float)(((double)returns[k] - mean) * inv); }
+}
+
+int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col) {
+    hipLaunchKernelGGL(k_adv_normalise, dim3(1), dim3(1024), 0, ppo_stream(), returns, idx_dev, B, adv_col);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}

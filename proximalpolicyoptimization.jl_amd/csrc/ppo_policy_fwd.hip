@@ -324,12 +324,12 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 }
 
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
-                                int64_t B_global, double eps, double entropy_weight) {
+                                int64_t B_global, double eps, double entropy_weight, const float* adv_col) {
     FwdArgs a = {};
     fill_weights(p, a);
     a.states = ro->states.p; a.active = ro->active.p; a.idx = idx_dev; a.B = B;
     a.act1 = (float4*)p->act1.p; a.act2 = (float4*)p->act2.p; a.dY = (float4*)p->dY.p; a.loss_terms = p->loss_terms.p;
-    a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = ro->returns.p;
+    a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = adv_col;
     a.eps = eps; a.c_over_B = (float)(entropy_weight / (double)B_global); a.inv_B = (float)(1.0 / (double)B_global);
     ProfScope ps("k_policy_fwd_train");
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 2, B, ro->H / 32);

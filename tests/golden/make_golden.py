@@ -2,6 +2,7 @@
 /root/reference does not exist on the GPU box).  No reference source text is copied: only
   - output/trajectory.csv                  (known-answer returns)
   - output/states/sample_1.bson            (183-byte wire-format fixture)
+  - test/output/poly-30-policy.bson        (checkpoint wire-format fixture, copied as is)
   - test/output/*.bson                     (trained Float32 policy weights),
     decoded with pymongo's `bson` (a pure data decoder, executes nothing) and re-saved as .npz
     in flat Flux order (W1,b1,W2,b2,W3,b3; W [out,in] column-major).
@@ -47,6 +48,8 @@ def decode_policy(path):
 def main():
     shutil.copy(os.path.join(REF, "output/trajectory.csv"), os.path.join(OUT, "trajectory.csv"))
     shutil.copy(os.path.join(REF, "output/states/sample_1.bson"), os.path.join(OUT, "sample_1.bson"))
+    # one trained-policy checkpoint as BSON.jl wrote it (data file; wire-format fixture of the checkpoint interop)
+    shutil.copy(os.path.join(REF, "test/output/poly-30-policy.bson"), os.path.join(OUT, "poly-30-policy.bson"))
     for name in ["catmull-clark-policy-l4", "poly-30-policy", "catmull-clark-policy"]:
         flat, shapes = decode_policy(os.path.join(REF, "test/output", name + ".bson"))
         sh = np.array([s + [0] * (2 - len(s)) for s in shapes], np.int64)   # vectors -> [n,0]

@@ -308,6 +308,33 @@ def test_gradient_clipped_branch(P, orc):
         assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
 
 
+def test_normalised_advantage_mode(P, orc):
+    """batch_advantage plugin, "returns_normalised": (R - mean) / (std + 1e-8) over the minibatch (population std,
+    fp64 statistics, fp32 result).  The reference declares the plugin and ships no implementation
+    (src/ProximalPolicyOptimization.jl:29), so the oracle is the f64 gradient fed with advantages normalised on the host."""
+    env, pol, ro, ds = _make_dataset(P, orc, 24, 12, 128, seed=5)
+    rng = np.random.default_rng(1)
+    for B in (7, 64, 200):
+        sel = rng.permutation(len(ds))[:B] + 1
+        lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="returns_normalised")
+        g = pol.grad()
+        st, act = ro.state_data
+        s0 = sel - 1
+        R = ro.rewards.reshape(-1)[s0].astype(np.float64)
+        advn = ((R - R.mean()) / (R.std() + 1e-8)).astype(np.float32)
+        g64, olp, ole = orc.step_batch_grad_f64(pol.params, 72, 128, st.reshape(-1, 32, 72)[s0], act.reshape(-1)[s0],
+                                                (ro.selected_actions.reshape(-1)[s0] - 1).astype(np.int32),
+                                                ro.selected_action_probabilities.reshape(-1)[s0], advn, 0.05, 0.01)
+        assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+        assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    with pytest.raises(P.PPOError):
+        P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="gae")
+    # a whole ppo_train! epoch in this mode runs and changes the parameters
+    before = pol.params.copy()
+    P.ppo_train_(pol, P.Optimiser(P.Adam(1e-3)), ds, 0.05, 64, 1, 0.01, seed=3, verbose=False, advantage="returns_normalised")
+    assert np.all(np.isfinite(pol.params)) and not np.array_equal(before, pol.params)
+
+
 def test_step_batch_adam_bitexact(P, orc):
     """Flux.update! with legacy Adam: parameters after the step are bit-identical to the oracle's Adam
     applied to the device gradient (element arithmetic in fp64, fp32 stores)."""
