@@ -44,6 +44,10 @@ mutable struct HipPolicy
     end
 end
 
+# arithmetic of the MLP's Dense products: :f32 (Flux's Float32, default) or :bf16 (bf16 MFMA, fp32 accumulation)
+set_dtype!(p::HipPolicy, dtype::Symbol) =
+    check(ccall((:ppo_policy_set_dtype, LIB), Int32, (Ptr{Cvoid}, Int32), p.h, dtype === :bf16 ? 1 : 0))
+
 # Flux.params(policy) round trip: flat vector in Flux order (W1,b1,W2,b2,W3,b3), W [out,in] column-major
 set_params!(p::HipPolicy, flat::Vector{Float32}) =
     check(ccall((:ppo_policy_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), p.h, flat))
@@ -127,13 +131,16 @@ function Base.length(r::HipRollouts)
 end
 PPO.construct_dataset(r::HipRollouts) = r              # dataset == non-owning view of the same handle
 
+# batch_advantage plugin mode handed to the engine: 0 = returns (PPO.batch_advantage above), 1 = normalised returns
+const ADV_MODE = Ref{Int32}(0)
+
 function PPO.ppo_train!(p::HipPolicy, optimizer, r::HipRollouts, epsilon, batch_size, num_epochs, entropy_weight)
     adam = first(optimizer)::HipAdam
     ph, eh, lh = zeros(num_epochs), zeros(num_epochs), zeros(num_epochs)
     check(ccall((:ppo_train, LIB), Int32,
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int32, Float64, Int32, Ptr{Int64}, UInt64, Int32,
                  Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                p.h, adam.h, r.h, epsilon, batch_size, num_epochs, entropy_weight, 0, C_NULL, rand(UInt64), 1,
+                p.h, adam.h, r.h, epsilon, batch_size, num_epochs, entropy_weight, ADV_MODE[], C_NULL, rand(UInt64), 1,
                 C_NULL, C_NULL, ph, eh, lh))
     for e in 1:num_epochs
         PPO.@printf "EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e\n" e ph[e] eh[e] lh[e]

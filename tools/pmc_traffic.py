@@ -24,5 +24,5 @@ for k, v in acc.items():
     out[k] = {"fetch_bytes_corrected": 2 * fe * 1024, "write_bytes": wr * 1024, "hbm_bytes": 2 * fe * 1024 + wr * 1024,
               "launches_sampled": len(v["FETCH_SIZE"])}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --t-steps 8 --epochs 1, 4096 states per launch",
-           "kernels": out}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+           "kernels": out}, open(sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/final/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
