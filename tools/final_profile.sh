@@ -23,5 +23,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $F/tra
 rm -f $F/trace_bf16/*/*kernel_trace.csv
 timeout -k 10 300 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --dtype bf16 --envs 65536 > $F/bench_bf16_c5.json 2> $F/bench_bf16_c5.err || { tail -5 $F/bench_bf16_c5.err; exit 1; }
 # 5. does VALU work hide under the fp32 MFMA?  
+for w in 1 2; do [ -x tools/microbench/mfma_valu_w$w ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -DWPS=$w -o tools/microbench/mfma_valu_w$w tools/microbench/mfma_f32_valu_overlap.hip > /dev/null 2>&1; done
 ( timeout -k 5 60 ./tools/microbench/mfma_valu_w1 && timeout -k 5 60 ./tools/microbench/mfma_valu_w2 ) > $F/mfma_f32_valu_overlap.txt 2>&1 || true
 ls $F $F/trace/* $F/trace_bf16/*
