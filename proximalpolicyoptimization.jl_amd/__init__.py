@@ -34,6 +34,8 @@ import numpy as np
 
 from . import _lib
 from . import checkpoint  # noqa: F401
+from . import generic  # noqa: F401
+from .generic import HostDataset, HostRollouts  # noqa: F401
 from ._lib import PPOError, call, lib
 from .disk import (DiskDataset, DiskRollouts, bson_decode_state, bson_encode_state, export_reference_layout,  # noqa: F401
                    update_, write_returns_to_disk)
@@ -47,6 +49,9 @@ __all__ = [
     "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
     "device_count", "average_returns", "DiskRollouts", "DiskDataset", "update_", "write_returns_to_disk",
     "export_reference_layout", "load_disk_rollouts", "bson_encode_state", "bson_decode_state", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
+    "HostRollouts", "HostDataset", "update_rollouts_", "compute_state_value_", "collect_step_data_", "collect_episode_data_",
+    "permute_", "shuffle_", "single_trajectory_return", "smoothed_entropy", "clamped_entropy", "ppo_loss", "step_epoch_",
+    "save_policy", "load_policy", "forward_backward",
 ]
 
 
@@ -128,6 +133,8 @@ class StateData:
 @batch_state.register(list)
 def _(states):
     """PPO.batch_state (test/quad_game_utilities.jl:26-33): cat along the batch dimension."""
+    if not states or not all(isinstance(x, StateData) for x in states):
+        _not_implemented("batch_state")          # the reference dispatches on the element type: no method, no batch
     vs = np.stack([np.asarray(s.vertex_score, np.int8) for s in states])
     am = np.array([np.uint32(s.action_mask) for s in states], np.uint32)
     return StateData(vs, am)
@@ -468,6 +475,7 @@ class BufferRollouts:
     def __init__(self):
         self._h = None
         self._env = None
+        self._host = None        # generic (user-defined env) mode: the reference's own AoS columns (generic.HostRollouts)
 
     def _ensure(self, env, T):
         if self._h is None:
@@ -485,6 +493,8 @@ class BufferRollouts:
             pass
 
     def __len__(self):                                     # Base.length (src/rollout_buffer.jl:40-48)
+        if self._h is None and self._host is not None:
+            return len(self._host)
         if self._h is None:
             return 0
         n = C.c_int64(0)
@@ -572,8 +582,17 @@ def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     """PPO.collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79,
     src/rollouts_to_disk.jl:134-147).  The N resident envs each play ceil(num_episodes / N) whole episodes
     (reset! before each).  A DiskRollouts target additionally gets the reference's CSV + BSON layout."""
-    if not isinstance(env, HipVecEnv) or not isinstance(policy, HipPolicy):
-        _not_implemented("state")
+    if not isinstance(env, HipVecEnv):
+        # generic method: the reference's own per-step control flow over the user's plugin methods (an env without a
+        # `state` method raises "Function state needs to be overloaded" from inside it, like the reference)
+        if isinstance(rollouts, DiskRollouts):
+            raise PPOError(-4, "DiskRollouts with a user-defined env: use update_ / write_returns_to_disk (disk.py)")
+        if rollouts._host is None:
+            rollouts._host = HostRollouts()
+        generic.collect_rollouts_host_(_this_module(), rollouts._host, env, policy, num_episodes, discount)
+        return
+    if not isinstance(policy, HipPolicy):
+        _not_implemented("action_probabilities")
     if isinstance(rollouts, DiskRollouts):
         print("\n\nCOLLECTING ROLLOUTS :")                              # src/rollouts_to_disk.jl:141
         dev = BufferRollouts()
@@ -650,8 +669,33 @@ class BufferDataset:
         raise PPOError(-1, "Dataset index should be Int or Array, got %s" % type(idx).__name__)   # :141
 
 
+def _this_module():
+    import sys
+    return sys.modules[__name__]
+
+
+def _upload_host_rollouts(rollouts):
+    """HostRollouts of StateData states -> device buffer (ppo_rollouts_set), so ppo_train_ runs the MFMA path."""
+    h = rollouts._host
+    vs = np.stack([np.asarray(s.vertex_score, np.int8) for s in h.state_data])
+    if vs.ndim != 3 or vs.shape[2] != 72 or vs.shape[1] not in (32, 128):
+        raise PPOError(-4, "states must be [H,72] int8 with H in {32,128} for the gfx950 kernels")
+    carrier = HipVecEnv(num_envs=1, Q=vs.shape[1] // 4, max_actions=max(1, len(h)))
+    dev = BufferRollouts()
+    dev.set_columns(carrier, vs[:, None], np.array([[np.uint32(s.action_mask)] for s in h.state_data], np.uint32),
+                    np.asarray(h.selected_actions, np.int64)[:, None],
+                    np.asarray(h.selected_action_probabilities, np.float32)[:, None],
+                    np.asarray(h.rewards, np.float32)[:, None], np.asarray(h.terminal, np.uint8)[:, None])
+    return dev
+
+
 def construct_dataset(rollouts):
     """construct_dataset (src/rollout_buffer.jl:145-147, src/rollouts_to_disk.jl:169-171)."""
+    if isinstance(rollouts, BufferRollouts) and rollouts._h is None and rollouts._host is not None:
+        if len(rollouts._host) and all(isinstance(s, StateData) for s in rollouts._host.state_data):
+            rollouts._device = _upload_host_rollouts(rollouts)
+            return BufferDataset(rollouts._device)
+        return HostDataset(_this_module(), rollouts._host)
     if isinstance(rollouts, DiskRollouts):
         if rollouts._device is not None:
             return BufferDataset(rollouts._device)       # columns are still resident: no reload needed
@@ -763,6 +807,8 @@ def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size,
 def average_returns(policy, env, num_trajectories):
     """PPO.average_returns(policy, env, num_trajectories) (src/evaluate.jl:18-25) -> (mean, std) of the
     undiscounted episode return under the stochastic policy (std with the n-1 correction like Flux.std)."""
+    if not isinstance(env, HipVecEnv):
+        return generic.average_returns_host(_this_module(), policy, env, num_trajectories)
     scratch = BufferRollouts()
     per_env = -(-int(num_trajectories) // env.N)
     h = scratch._ensure(env, per_env * env.max_actions)
@@ -829,3 +875,72 @@ def save_policy(path, policy):
 def load_policy(path, seed=0, dtype="f32"):
     """BSON.@load path policy -> HipPolicy holding the saved Float32 weights (e.g. the reference's test/output/*.bson)."""
     return checkpoint.load_policy(path, HipPolicy, seed=seed, dtype=dtype)
+
+
+# ---------------------------------------------------------------- remaining reference entry points (host mirrors)
+def update_rollouts_(buffer, state, action_probability, action, reward, terminal):
+    """update!(buffer::BufferRollouts, ...) (src/rollout_buffer.jl:24-38) for user-driven collection."""
+    if buffer._host is None:
+        buffer._host = HostRollouts()
+    generic.update_host_(buffer._host, state, action_probability, action, reward, terminal)
+
+
+def compute_state_value_(rollouts, discount):
+    """compute_state_value!(rollouts, discount) (src/rollout_buffer.jl:55-64), generic (host-collected) rollouts."""
+    generic.compute_state_value_(_this_module(), rollouts._host, discount)
+
+
+def collect_step_data_(buffer, env, policy, rng=None):
+    """collect_step_data!(buffer, env, policy) (src/collect_rollouts.jl:1-15)."""
+    if buffer._host is None:
+        buffer._host = HostRollouts()
+    generic.collect_step_data_(_this_module(), buffer._host, env, policy, rng or np.random.default_rng())
+
+
+def collect_episode_data_(buffer, env, policy, rng=None):
+    """collect_episode_data!(buffer, env, policy) (src/collect_rollouts.jl:17-24)."""
+    if buffer._host is None:
+        buffer._host = HostRollouts()
+    generic.collect_episode_data_(_this_module(), buffer._host, env, policy, rng or np.random.default_rng())
+
+
+def permute_(rollouts, idx):
+    """permute!(rollouts, idx) (src/rollout_buffer.jl:81-88)."""
+    generic.permute_(rollouts._host, idx)
+
+
+def shuffle_(rollouts, rng=None):
+    """shuffle!(rollouts) (src/rollout_buffer.jl:90-93)."""
+    generic.shuffle_(rollouts._host, rng)
+
+
+def single_trajectory_return(policy, env, rng=None):
+    """single_trajectory_return(policy, env) (src/evaluate.jl:1-16)."""
+    return generic.single_trajectory_return(_this_module(), policy, env, rng)
+
+
+def smoothed_entropy(probs_AB, smooth=np.float32(1e-8)):
+    """smoothed_entropy(probs, smooth) (src/train.jl:21-26) on probs [A,B] -> mean entropy (Float32 arithmetic)."""
+    p = np.asarray(probs_AB, np.float32)
+    sp = (np.float32(1.0) - np.float32(smooth)) * p + np.float32(smooth) / np.float32(p.shape[0])
+    return float(np.mean(-np.sum(sp * np.log(sp), axis=0, dtype=np.float32), dtype=np.float32))
+
+
+def clamped_entropy(probs_AB, clamp=np.float32(1e-8)):
+    """clamped_entropy(probs, clamp) (src/train.jl:28-33; unused by the reference's training loop)."""
+    p = np.clip(np.asarray(probs_AB, np.float32), np.float32(clamp), None)
+    return float(np.mean(-np.sum(p * np.log(p), axis=0, dtype=np.float32), dtype=np.float32))
+
+
+def ppo_loss(probs_AB, linear_action_index, old_action_probabilities, advantage, epsilon):
+    """ppo_loss (src/train.jl:9-19): the clipped-surrogate term alone (ppo_loss_with_entropy without the entropy)."""
+    return ppo_loss_with_entropy(probs_AB, linear_action_index, old_action_probabilities, advantage, epsilon)[0]
+
+
+def step_epoch_(policy, optimizer, dataset, epsilon, batch_size, entropy_weight, perm=None, seed=0, advantage="returns"):
+    """step_epoch!(policy, optimizer, dataset, epsilon, batch_size, entropy_weight) (src/train.jl:86-128):
+    one pass over a fresh permutation; returns the unweighted means of the per-batch losses (:127)."""
+    p, e, _ = ppo_train_(policy, optimizer, dataset, epsilon, batch_size, 1, entropy_weight,
+                         perm=None if perm is None else np.asarray(perm)[None, :], seed=seed, verbose=False,
+                         advantage=advantage)
+    return p[0], e[0]
