@@ -186,6 +186,12 @@ def main():
             roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
+                    # context for `frac` (profiles/r01_mfma_f32_valu_overlap.txt): on gfx950 the fp32 MFMA
+                    # runs on the packed-fp32 vector ALU and vector instructions do not hide under it
+                    "ceiling_note": None if args.dtype != "f32" else
+                    "pure v_mfma_f32_32x32x2_f32 chain measured 140-143 TFLOP/s on this chip (clock under load); every "
+                    "vector instruction between MFMAs adds ~2 ns per SIMD: instruction-mix ceiling of this kernel "
+                    "(2432 MFMA + ~5250 vector instr per tile) ~125-130 TFLOP/s",
                     "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
                     "algorithmic_hbm_bytes_per_launch": MINIBATCH * (2 * HID * 32 * 4 + 32 * F + 32 * 16) + 256 * 4 *
                     (HID * HID + HID * 96 + HID * 6 + 4)}

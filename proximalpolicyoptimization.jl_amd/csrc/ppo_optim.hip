@@ -74,13 +74,22 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     if (canon >= 0) grad[canon] = s;
 }
 
-// loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global
+// loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global.
+// One block of 256 threads, fixed order: 8 interleaved fp64 partial sums per thread (loads in flight), a fixed tree
+// per thread, then the LDS tree.
 __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
                                   float* __restrict__ grad_tail) {
     __shared__ double s0[256], s1[256];
-    double a = 0.0, b = 0.0;
-    for (int64_t i = threadIdx.x; i < B; i += 256) { a += terms[2 * i]; b += terms[2 * i + 1]; }
-    s0[threadIdx.x] = a; s1[threadIdx.x] = b;
+    const double2* t2 = reinterpret_cast<const double2*>(terms);
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}, b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < B; i += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double2 v = t2[i + u * 256]; a[u] += v.x; b[u] += v.y; }
+    }
+    for (int u = 0; i < B; i += 256, ++u) { const double2 v = t2[i]; a[u] += v.x; b[u] += v.y; }
+    s0[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    s1[threadIdx.x] = ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off) { s0[threadIdx.x] += s0[threadIdx.x + off]; s1[threadIdx.x] += s1[threadIdx.x + off]; }
