@@ -8,8 +8,8 @@
 //     dW2[f-tile w, all k]  (NT 32x32 accumulators)   dW1[k-tile w, all i]  (NI accumulators)
 // Per tile:
 //   A  activations saved by the forward kernel in accumulator-fragment order come back with
-//      coalesced 1 KiB wave loads and are TRANSPOSED THROUGH LDS ([feature][33] fp32, conflict-free
-//      for both the row-major B reads and the feature-major A reads): dZ2 = (W3^T dY) . lrelu'(H2)
+//      coalesced 1 KiB wave loads and are TRANSPOSED THROUGH LDS ([feature][36] fp32, conflict-free
+//      for the row-major B reads and for the 16-byte feature-major reads of phases C/D): dZ2 = (W3^T dY) . lrelu'(H2)
 //   B  dH1^T = W2^T * dZ2^T  (A operand: pre-packed W2^T fragments streamed from L2, B operand:
 //      dZ2 from LDS); dZ1 = dH1 . lrelu'(H1) -> LDS.     The tiny grads (dW3, db*) are VALU sums.
 //   C  dW2 += dZ2 * H1^T     (contraction over the 32 rows: both operands read transposed from LDS)
@@ -21,6 +21,13 @@
 #include "ppo_internal.h"
 #include "ppo_device.h"
 #include <cstdlib>
+
+#ifndef PPO_BWD_LD
+#define PPO_BWD_LD 36
+#endif
+#ifndef PPO_BWD_KG
+#define PPO_BWD_KG 2
+#endif
 
 struct BwdArgs {
     unsigned long long* stamps;   // diagnostic build only (-DPPO_BWD_STAMP): [nwg][2 waves][6 phases]
@@ -41,7 +48,13 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     constexpr int NIM = F / 32;                 // full 32-column i-tiles done on the MFMA pipe
     constexpr int FT = F % 32;                  // tail columns (8 for F=72, 24 for F=216): VALU beside the MFMAs
     static_assert(FT % 4 == 0, "F must be a multiple of 4");
-    constexpr int LD = 33;                      // padded leading dimension (rows) of the LDS tiles
+    // leading dimension (rows) of the LDS tiles: 36 = 4*9 keeps every row 16-byte aligned and makes the 16 lanes of a
+    // ds_read_b128 group (consecutive features, 36 dwords apart) cover the 64 banks exactly once, so the products that
+    // contract over the 32 rows fetch FOUR consecutive rows per LDS instruction (row = 16*half + step: the k-slot
+    // order of an MFMA contraction is free as long as A and B agree).  Beside the fp32 MFMA an LDS read costs the same
+    // ~6 ns whether it returns 4 or 16 bytes per lane (tools/microbench/mfma_f32_lds_overlap.hip), and these kernels
+    // issued one ds_read_b32 per MFMA.
+    constexpr int LD = PPO_BWD_LD;
     constexpr int XDW = 32 * F / 4;             // dwords of one state
     constexpr int XPD = (XDW + NTHR - 1) / NTHR;  // state dwords staged per thread
     constexpr int PF = (HID >= 256) ? 2 : 4;    // W2^T fragment groups per register set (two sets, ping-ponged)
@@ -208,14 +221,13 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             const float* gy = sDY + 64 * h;
             float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll 1
-            for (int rc = 0; rc < 16; rc += 4) {                   // reads of 4 rows first, then the arithmetic
-                float z[4], hv[4];
+            for (int rc = 0; rc < 16; rc += 4) {                   // one 16-byte read per operand covers 4 rows
+                const float4 z4 = *reinterpret_cast<const float4*>(gz + rc);
+                const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
+                const float z[4] = {z4.x, z4.y, z4.z, z4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
                 float4 y[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    z[i] = gz[rc + i]; hv[i] = gh[rc + i];
-                    y[i] = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
-                }
+                for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -300,11 +312,11 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             // read / lgkmcnt(0) / use for every single read: ~40 serialized LDS round trips per tile)
 #pragma unroll 1
             for (int rc = 0; rc < 16; rc += 4) {
-                float z[4];
+                const float4 z4 = *reinterpret_cast<const float4*>(g1 + rc);
+                const float z[4] = {z4.x, z4.y, z4.z, z4.w};
                 float4 xv[4][FT / 4 > 0 ? FT / 4 : 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    z[i] = g1[rc + i];
 #pragma unroll
                     for (int c4 = 0; c4 < FT / 4; ++c4) xv[i][c4] = *reinterpret_cast<const float4*>(xt + (rc + i) * FT + 4 * c4);
                 }
@@ -324,17 +336,25 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         };
         if (grads_first) tail_grads();
         {
-            const float* pa = sZ2 + (32 * w + j) * LD + h;
-            const float* pb = sH1 + j * LD + h;
-#pragma unroll 2
-            for (int s = 0; s < 16; ++s) {
-                const float av = pa[2 * s];
-                float bv[NT];
+            constexpr int KG = PPO_BWD_KG;                           // k-tiles whose B operands are in flight together
+            const float* pa = sZ2 + (32 * w + j) * LD + 16 * h;      // rows 16h .. 16h+15 of this lane's feature
+            const float* pb = sH1 + j * LD + 16 * h;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {                            // 4 rows per LDS read
+                const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt) bv[kt] = pb[32 * kt * LD + 2 * s];
+                for (int kh = 0; kh < NT; kh += KG) {
+                    float4 b4[KG];
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt)
-                    accW2[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kt], accW2[kt], 0, 0, 0);
+                    for (int u = 0; u < KG; ++u) b4[u] = *reinterpret_cast<const float4*>(pb + 32 * (kh + u) * LD + 4 * q);
+#pragma unroll
+                    for (int u = 0; u < KG; ++u) {
+                        accW2[kh + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[u].x, accW2[kh + u], 0, 0, 0);
+                        accW2[kh + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[u].y, accW2[kh + u], 0, 0, 0);
+                        accW2[kh + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[u].z, accW2[kh + u], 0, 0, 0);
+                        accW2[kh + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[u].w, accW2[kh + u], 0, 0, 0);
+                    }
+                }
             }
         }
         STAMP(7);
@@ -352,17 +372,21 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         }
         STAMP(8);
         {
-            const float* pa = sZ1 + (32 * w + j) * LD + h;
-            const float* pb = sX + j * LD + h;
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const float av = pa[2 * s];
-                float bv[NIM];
+            const float* pa = sZ1 + (32 * w + j) * LD + 16 * h;
+            const float* pb = sX + j * LD + 16 * h;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
+                float4 b4[NIM > 0 ? NIM : 1];
 #pragma unroll
-                for (int it = 0; it < NIM; ++it) bv[it] = pb[32 * it * LD + 2 * s];
+                for (int it = 0; it < NIM; ++it) b4[it] = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
 #pragma unroll
-                for (int it = 0; it < NIM; ++it)
-                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[it], accW1[it], 0, 0, 0);
+                for (int it = 0; it < NIM; ++it) {
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[it].x, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[it].y, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[it].z, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[it].w, accW1[it], 0, 0, 0);
+                }
             }
         }
         STAMP(9);
@@ -425,7 +449,7 @@ extern "C" int32_t ppo_debug_bwd_stamps(unsigned long long* out) {
 
 template <int F, int HID>
 static size_t bwd_lds_bytes() {
-    return sizeof(float) * ((size_t)4 * HID * 33 + (size_t)(F / 32) * 32 * 33 + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
+    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + (size_t)(F / 32) * 32 * PPO_BWD_LD + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
                             (size_t)HID * 4);
 }
 
