@@ -45,7 +45,15 @@ __device__ __forceinline__ float exp_dev(float x) {
     return y * __uint_as_float((uint32_t)e << 23);
 }
 
-__device__ __forceinline__ float lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
+// leakyrelu(x) = x > 0 ? x : 0.01x == max(x, 0.01x) for every finite x (slope < 1), bit for bit including +-0.
+// v_mul + v_max instead of v_mul + v_cmp + v_cndmask: on gfx950 every vector instruction beside an fp32 MFMA costs
+// MFMA time.  Inline asm because fmaxf() lowers to two v_max (an extra canonicalising one).
+__device__ __forceinline__ float lrelu(float x) {
+    const float y = 0.01f * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 // feature held by accumulator register r of 32x32 tile `tile` in lane-half hh (gfx950 C/D map)
 __device__ __host__ __forceinline__ int dfeat(int tile, int r, int hh) {

@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, xf[4 * s4 + 2], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xf[4 * s4 + 3], acc, 0, 0, 0);
                     }
+                    // the epilogue reads the tile with VALU instructions: ask for VGPRs (hipcc otherwise parks the
+                    // accumulator in AGPRs and copies it out with 16 v_accvgpr_read per tile)
+                    asm volatile("" : "+v"(acc));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
                     h1[o] = acc;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                         }
                     }
                     FSTAMP(2);
+                    asm volatile("" : "+v"(acc));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
                     if (MODE == 2 && PPO_FWD_STORE) {
