@@ -82,10 +82,13 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline line); bf16 = the config-5 arithmetic on the same workload "
                          "(flagged in the output, not the headline)")
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default 4096 = the headline workload)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, BASELINE config 3): 4096 envs and a 4096-sample minibatch PER GPU; strong: the 4096 envs "
+                         "and the 4096-sample global minibatch are split over the GPUs (flagged in the output)")
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
-    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS)
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak")
     N_ENVS = MINIBATCH = args.envs
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,6 +96,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.scaling == "strong":
+        if N_ENVS % world:
+            raise SystemExit("--scaling strong needs the env count to divide by the number of GPUs")
+        N_ENVS = MINIBATCH = N_ENVS // world
 
     import ctypes as C
     import ppo_amd as PPO
@@ -204,7 +211,7 @@ def main():
         out = {
             "metric": "env-steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=8,H=32,A=128,F=72 int8), "
                                    "2x256 MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
