@@ -314,23 +314,26 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             for (int rc = 0; rc < 16; rc += 4) {
                 const float4 z4 = *reinterpret_cast<const float4*>(g1 + rc);
                 const float z[4] = {z4.x, z4.y, z4.z, z4.w};
-                float4 xv[4][FT / 4 > 0 ? FT / 4 : 1];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int ib = 0; ib < 4; ib += 2) {            // two rows of X tail columns in flight (register budget)
+                    float4 xv[2][FT / 4 > 0 ? FT / 4 : 1];
 #pragma unroll
-                    for (int c4 = 0; c4 < FT / 4; ++c4) xv[i][c4] = *reinterpret_cast<const float4*>(xt + (rc + i) * FT + 4 * c4);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s1 += z[i];
-#pragma unroll
-                    for (int c4 = 0; c4 < FT / 4; ++c4) {
-                        tl[4 * c4 + 0] = fmaf(z[i], xv[i][c4].x, tl[4 * c4 + 0]); tl[4 * c4 + 1] = fmaf(z[i], xv[i][c4].y, tl[4 * c4 + 1]);
-                        tl[4 * c4 + 2] = fmaf(z[i], xv[i][c4].z, tl[4 * c4 + 2]); tl[4 * c4 + 3] = fmaf(z[i], xv[i][c4].w, tl[4 * c4 + 3]);
+                        for (int c4 = 0; c4 < FT / 4; ++c4) xv[i][c4] = *reinterpret_cast<const float4*>(xt + (rc + ib + i) * FT + 4 * c4);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        s1 += z[ib + i];
+#pragma unroll
+                        for (int c4 = 0; c4 < FT / 4; ++c4) {
+                            tl[4 * c4 + 0] = fmaf(z[ib + i], xv[i][c4].x, tl[4 * c4 + 0]); tl[4 * c4 + 1] = fmaf(z[ib + i], xv[i][c4].y, tl[4 * c4 + 1]);
+                            tl[4 * c4 + 2] = fmaf(z[ib + i], xv[i][c4].z, tl[4 * c4 + 2]); tl[4 * c4 + 3] = fmaf(z[ib + i], xv[i][c4].w, tl[4 * c4 + 3]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             db1 += s1;
         };
@@ -377,15 +380,13 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
-                float4 b4[NIM > 0 ? NIM : 1];
-#pragma unroll
-                for (int it = 0; it < NIM; ++it) b4[it] = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
 #pragma unroll
                 for (int it = 0; it < NIM; ++it) {
-                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[it].x, accW1[it], 0, 0, 0);
-                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[it].y, accW1[it], 0, 0, 0);
-                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[it].z, accW1[it], 0, 0, 0);
-                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[it].w, accW1[it], 0, 0, 0);
+                    const float4 b4 = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accW1[it], 0, 0, 0);
+                    accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, accW1[it], 0, 0, 0);
                 }
             }
         }
