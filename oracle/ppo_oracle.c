@@ -539,7 +539,14 @@ void orc_collect_rollouts_tn(orc_env* e, const float* params, int32_t HID, int32
             orc_philox4x32_10(ctr, key, w);
             int32_t err = 0;
             int32_t a = orc_categorical_sample(probs, A, orc_u01(w[0]), &err);  /* :6-7 */
-            if (err) e->err[n] |= 8;
+            if (err) {
+                /* the walk ran off the end of a masked distribution (fp32 sum of the probabilities < u): the engine
+                 * gives the rounding residue to the last action with p > 0 instead of throwing like the reference's
+                 * @assert would (flag 32, informational); no positive entry at all is still an error (flag 8) */
+                int32_t best = -1;
+                for (int32_t q = 0; q < A; ++q) if (probs[q] > 0.0f) best = q;
+                if (best >= 0) { a = best; e->err[n] |= 32; } else e->err[n] |= 8;
+            }
             orc_env_step_one(e, n, a);                                        /* :9 */
             p_sel[idx] = probs[a]; actions[idx] = a;                          /* :14 update! */
             rewards[idx] = e->reward[n]; done[idx] = e->done[n];              /* :11-12 */

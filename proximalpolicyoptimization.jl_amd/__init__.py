@@ -185,6 +185,14 @@ class HipVecEnv:
         except Exception:
             pass
 
+    def error_flags(self):
+        """OR of the device-side flags since creation: 1 action on an inactive quad, 2 index out of range, 4 step! on a
+        terminated env, 8 sampled action with probability 0 (the reference's @assert), 32 informational: a CDF
+        rounding residue was handed to the last unmasked action (numerics contract)."""
+        f = C.c_int32(0)
+        lib().ppo_env_check_errors(self._h, C.byref(f))
+        return f.value
+
     def internal(self):
         V = 4 * self.Q
         sc = np.empty((self.N, V), np.int8)

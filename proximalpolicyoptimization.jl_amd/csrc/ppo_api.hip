@@ -264,7 +264,7 @@ int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null) {
     int32_t f = 0;
     PPO_TRY(d2h(&f, env->err.p, 1));
     if (flags_or_null) *flags_or_null = f;
-    if (f) {
+    if (f & ~32) {                  // bit 32 is informational: a CDF rounding residue went to the last unmasked action
         std::string m = "AssertionError (device flag):";
         if (f & 1) m += " action on inactive quad;";
         if (f & 2) m += " action index out of range;";

@@ -106,9 +106,33 @@ __device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t stat
         for (int ts = 0; ts < TPS; ++ts)
 #pragma unroll
             for (int i = 0; i < 4; ++i) cand = ((ia >> 7) == ts && (ia & 3) == i) ? p[ts][i] : cand;
-        const float psel = __shfl(cand, (ia & 127) >> 2);
+        float psel = __shfl(cand, (ia & 127) >> 2);
+        if (!(psel > 0.0f)) {                            // wave-uniform, about 3 in 10^8 samples
+            // The walk ran off the end: the sequential fp32 sum of the probabilities fell short of u (u within a few
+            // 2^-24 of 1).  Distributions.jl lets the LAST bin absorb that rounding residue; when the last action is
+            // masked its probability is 0 and the reference's `@assert ap[a] > 0.0` throws -- at 10^6 samples per
+            // iteration that would abort a run every few iterations.  The engine hands the residue to the last action
+            // with non-zero probability instead (flag bit 32, informational); a distribution without any positive
+            // entry still raises (bit 8).
+            int best = -1;
+#pragma unroll
+            for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) best = (p[ts][i] > 0.0f) ? 128 * ts + 4 * j + i : best;    // ascending: last wins
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+            if (best >= 0) {
+                ia = best;
+                cand = 0.0f;
+#pragma unroll
+                for (int ts = 0; ts < TPS; ++ts)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cand = ((ia >> 7) == ts && (ia & 3) == i) ? p[ts][i] : cand;
+                psel = __shfl(cand, (ia & 127) >> 2);
+            }
+            if (lane == 0) atomicOr(a.err, best >= 0 ? 32 : 8);
+        }
         if (lane == 0) {
-            if (!(psel > 0.0f)) atomicOr(a.err, 8);     // @assert ap[a] > 0.0
             a.actions_out[state] = ia;
             a.psel_out[state] = psel;
         }

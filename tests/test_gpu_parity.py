@@ -220,6 +220,39 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions):
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
 
 
+def test_cdf_residue_goes_to_last_unmasked_action(P, orc):
+    """u = 1 - 2^-24 (the largest uniform) against a distribution whose sequential fp32 sum stops at or below it: the
+    walk runs off the end onto a masked action (p = 0), where the reference's `@assert ap[a] > 0.0` would throw
+    (src/collect_rollouts.jl:7).  The engine and the oracle give the residue to the last action with p > 0 (flag 32).
+    The (seed, env id, tick) triples below were found by scanning Philox4x32-10 for w0 >> 8 == 0xFFFFFF."""
+    fired = 0
+    for seed, gid, t in [(1, 7173697, 1), (2, 2149053, 1), (3, 2350790, 0)]:
+        assert orc.u01(orc.philox([gid, t, 0, 0], [seed, 0])[0]) == 1.0 - 2.0 ** -24
+        for pseed in range(6):
+            N, T = 3, t + 1
+            env = P.HipVecEnv(num_envs=N, Q=8, max_actions=20, seed=seed, global_offset=gid - 1)
+            pol = P.HipPolicy(72, 128, 2, 4, seed=pseed)
+            ro = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro, env, pol, T, 1.0, record_probs=True)     # must not raise
+            oenv = orc.Env(Q=8, max_actions=20, N=N, seed=seed, global_offset=gid - 1)
+            oenv.reset()
+            ref = orc.collect_rollouts_tn(oenv, pol.params, 128, T, mode_dev=True)
+            assert np.array_equal(ro.selected_actions - 1, ref["actions"])
+            assert np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
+            assert np.all(ro.selected_action_probabilities > 0)
+            probs = ro.full_probs()[t, 1]
+            if env.error_flags() & 32:
+                fired += 1
+                a = int(ro.selected_actions[t, 1]) - 1
+                assert a == int(np.nonzero(probs > 0)[0].max()) and oenv.err[1] & 32
+                csum = np.float32(0)
+                for x in probs:
+                    csum = np.float32(csum + x)
+                assert csum <= np.float32(1.0 - 2.0 ** -24)
+            assert env.error_flags() & ~32 == 0
+    assert fired >= 1, "none of the candidates had a short fp32 sum: extend the candidate list"
+
+
 def test_rollout_episodes_mode_plumbing(P, orc):
     """BASELINE config 1: 1 env x 128-step rollout; whole episodes only (reference semantics)."""
     env = P.HipVecEnv(num_envs=1, Q=8, max_actions=128, seed=5)
