@@ -17,10 +17,11 @@
 // 16x the flops of the fp32 one per cycle, so the weight stream has to come from LDS: W2 (128 KiB as bf16 for
 // HID = 256) is staged once per workgroup, one ds_read_b128 per MFMA; W1 (36 KiB) streams through L1; layer 3
 // (HID x 4) is two more MFMAs per feature tile with a zero-padded A operand instead of 64 VALU FMAs.
-// Backward: a workgroup of HID/32 waves walks tiles; wave w owns feature tile w of every weight gradient
+// Backward (two kernels, see BwdB below): a workgroup of 4 waves walks tiles; wave w owns feature tiles w*FT.. of dW2
 // (accumulators resident all launch).  The lane-is-row tiles (dZ2, H1, dZ1, H2) are written once as row-major
 // bf16 images into LDS and come back TRANSPOSED through ds_read_b64_tr_b16 as the operands of the products that
-// contract over the 32 rows (dW2, dW1, dW3); dH1 = W2^T dZ2 takes dZ2 lane-linear in accumulator-fragment order.
+// contract over the 32 rows (dW2, dW3; dZ1 and X are emitted as fragments for the dW1 kernel); dH1 = W2^T dZ2
+// takes dZ2 lane-linear in accumulator-fragment order.
 #include "ppo_policy_tail.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
