@@ -852,7 +852,14 @@ class DataParallel:
 
     @staticmethod
     def allreduce_(tensor):
+        """Sum all-reduce in place.  "nccl" (= RCCL) reduces the device tensor on the current stream; with the "gloo"
+        backend (CPU rehearsal: several ranks sharing one GPU in the tests) a device tensor takes a host round trip."""
         import torch.distributed as dist
+        if tensor.is_cuda and dist.get_backend() == "gloo":
+            host = tensor.cpu()                       # synchronises with the stream the engine runs on
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            tensor.copy_(host)
+            return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         return tensor
 
