@@ -130,6 +130,22 @@ def test_bf16_gradient_vs_oracle(P, npo, HID, B, Q):
     assert np.array_equal(g, pol.grad()), "run-to-run bitwise reproducible"
 
 
+@pytest.mark.parametrize("B", [1, 2, 5, 255, 257])
+def test_bf16_gradient_ragged_batch_sizes(P, npo, B):
+    """Minibatches that do not fill the 256-workgroup grid (the dW1 kernel shares the tile -> workgroup assignment)."""
+    env, pol, ro, ds = _dataset(P, 30, 10, 256, seed=55)          # 300 samples
+    rng = np.random.default_rng(B)
+    sel = rng.integers(0, len(ds), size=B)
+    st, act = ro.state_data
+    masks = _masks(npo, act.reshape(-1)[sel], 8)
+    a0 = (ro.selected_actions.reshape(-1)[sel] - 1).astype(np.int64)
+    po, adv = ro.selected_action_probabilities.reshape(-1)[sel], ro.rewards.reshape(-1)[sel]
+    P.forward_backward(pol, ds, sel + 1, 10.0, 0.01)
+    g16, _, _ = npo.step_batch_grad_bf16(pol.params, 72, 256, st.reshape(-1, 32, 72)[sel], masks, a0, po, adv, 10.0, 0.01)
+    assert np.abs(pol.grad() - g16).max() <= 1e-2 * np.abs(g16).max()
+    assert np.linalg.norm(pol.grad() - g16) <= 3e-3 * np.linalg.norm(g16)
+
+
 def test_bf16_clipped_samples_carry_only_entropy_gradient(P, npo):
     env, pol, ro, ds = _dataset(P, 16, 8, 128, seed=3)
     sel = np.arange(64)

@@ -220,6 +220,49 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions):
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_rollout_bitexact_fuzz(P, orc, case):
+    """Randomised shapes / seeds / horizons / global offsets: whole rollouts stay bit-identical to the device-order
+    oracle (states, masks, sampled actions, probabilities, rewards, done flags, returns in both discount types)."""
+    rng = np.random.default_rng(1000 + case)
+    N = int(rng.integers(1, 70))
+    T = int(rng.integers(1, 40))
+    HID = int(rng.choice([128, 256]))
+    Q = int(rng.choice([8, 8, 32]))
+    max_actions = int(rng.integers(2, 30))
+    seed = int(rng.integers(0, 2 ** 31))
+    off = int(rng.integers(0, 2 ** 20))
+    gamma = [1.0, 0.99, np.float32(0.97)][case % 3]
+    env = P.HipVecEnv(num_envs=N, Q=Q, max_actions=max_actions, seed=seed, global_offset=off)
+    pol = P.HipPolicy(72, HID, 2, 4, seed=case)
+    pol.params = pol.params + (rng.normal(size=pol.num_params) * 0.05).astype(np.float32)
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, T, gamma)
+    oenv = orc.Env(Q=Q, max_actions=max_actions, N=N, seed=seed, global_offset=off)
+    oenv.reset()
+    ref = orc.collect_rollouts_tn(oenv, pol.params, HID, T, mode_dev=True)
+    st, act = ro.state_data
+    assert np.array_equal(st, ref["states"]) and np.array_equal(act, ref["active"])
+    assert np.array_equal(ro.selected_actions - 1, ref["actions"])
+    assert np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
+    assert np.array_equal(ro.raw_rewards, ref["rewards"]) and np.array_equal(ro.terminal, ref["done"].astype(bool))
+    assert np.array_equal(ro.rewards, orc.compute_returns_tn(ref["rewards"], ref["done"], float(gamma),
+                                                             isinstance(gamma, np.float32)))
+    assert env.error_flags() & ~32 == 0
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 31, 33, 255, 257])
+def test_gradient_ragged_batch_sizes(P, orc, B):
+    """Minibatches that do not fill the persistent grid (B = 1 ... 257 tiles on 256 workgroups) and repeat samples."""
+    env, pol, ro, ds = _make_dataset(P, orc, 30, 10, 256, seed=77)      # 300 samples
+    rng = np.random.default_rng(B)
+    sel = rng.integers(1, len(ds) + 1, size=B)
+    lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01)
+    g64, olp, ole = _oracle_grad(orc, pol.params, 256, ro, sel - 1, 0.05, 0.01)
+    assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+    assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+
+
 def test_cdf_residue_goes_to_last_unmasked_action(P, orc):
     """u = 1 - 2^-24 (the largest uniform) against a distribution whose sequential fp32 sum stops at or below it: the
     walk runs off the end onto a masked action (p = 0), where the reference's `@assert ap[a] > 0.0` would throw
