@@ -95,6 +95,12 @@ int32_t ppo_env_get_terminal(ppo_env_t env, uint8_t* out);              /* is_te
 int32_t ppo_env_get_internal(ppo_env_t env, int8_t* score, int8_t* degree, int32_t* steps,
                              uint32_t* episode, uint32_t* tick);
 int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null);
+/* rand(Categorical(ap)) walks the CDF sequentially; when the fp32 sum of ap stops short of u (u within 2^-24 of 1) the
+ * walk ends on the LAST action, and if that action is masked the reference's `@assert ap[a] > 0.0` throws
+ * (src/collect_rollouts.jl:7) -- about 3 in 10^8 samples.  Default (strict = 0): the residue goes to the last action
+ * with ap > 0 and flag bit 32 records it.  strict = 1: the rollout call fails with PPO_ERR_DEVICE_FLAG like the
+ * reference's AssertionError. */
+int32_t ppo_env_set_strict_sampling(ppo_env_t env, int32_t strict);
 
 /* ---------------------------------------------------------------- policy plugin */
 /* SimplePolicy.Policy(in, hidden, num_hidden_layers, out)  test/policy.jl:9-19 */

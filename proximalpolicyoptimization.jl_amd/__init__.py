@@ -169,13 +169,16 @@ class HipVecEnv:
     """N synthetic rand-poly-shaped envs resident on the GPU (ppo_env_*).  Not QuadMeshGame: the
     mesh dynamics are not in the reference tree ('Synthetic env')."""
 
-    def __init__(self, num_envs=1, Q=8, max_actions=128, no_action_reward=-4.0, seed=1234, global_offset=0):
+    def __init__(self, num_envs=1, Q=8, max_actions=128, no_action_reward=-4.0, seed=1234, global_offset=0,
+                 strict_sampling=False):
         h = C.c_void_p()
         call("ppo_env_create", 0, int(num_envs), int(global_offset), int(Q), int(max_actions), float(no_action_reward),
              int(seed), C.byref(h))
         self._h = h
         self.N, self.Q, self.H, self.F, self.A = int(num_envs), Q, 4 * Q, 72, 16 * Q
         self.max_actions = max_actions
+        if strict_sampling:      # reference behaviour: a CDF walk that ends on a masked action raises (@assert ap[a] > 0.0)
+            call("ppo_env_set_strict_sampling", h, 1)
 
     def __del__(self):
         try:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ppo_env_get_terminal": [H, c_u8p],
     "ppo_env_get_internal": [H, c_i8p, c_i8p, c_i32p, c_u32p, c_u32p],
     "ppo_env_check_errors": [H, c_i32p],
+    "ppo_env_set_strict_sampling": [H, C.c_int32],
     "ppo_policy_create": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, HP],
     "ppo_policy_set_dtype": [H, C.c_int32],
     "ppo_policy_get_dtype": [H, C.POINTER(C.c_int32)],

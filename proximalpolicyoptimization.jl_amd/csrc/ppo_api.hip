@@ -257,6 +257,8 @@ int32_t ppo_env_dims(ppo_env_t env, int64_t* N, int32_t* H, int32_t* F, int32_t*
     return PPO_OK;
 }
 
+int32_t ppo_env_set_strict_sampling(ppo_env_t env, int32_t strict) { ARG_CHECK(env, "null env"); env->strict_sampling = strict ? 1 : 0; return PPO_OK; }
+
 int32_t ppo_env_reset(ppo_env_t env) { ARG_CHECK(env, "reset!: null env"); return launch_env_reset(env, 0); }
 
 int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null) {
@@ -264,12 +266,13 @@ int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null) {
     int32_t f = 0;
     PPO_TRY(d2h(&f, env->err.p, 1));
     if (flags_or_null) *flags_or_null = f;
-    if (f & ~32) {                  // bit 32 is informational: a CDF rounding residue went to the last unmasked action
+    if (f & ~(env->strict_sampling ? 0 : 32)) {     // bit 32 is informational unless strict: a CDF rounding residue went to the last unmasked action
         std::string m = "AssertionError (device flag):";
         if (f & 1) m += " action on inactive quad;";
         if (f & 2) m += " action index out of range;";
         if (f & 4) m += " step! on a terminated env;";
         if (f & 8) m += " sampled action has probability 0 (ap[a] > 0.0 failed, src/collect_rollouts.jl:7);";
+        if (f & 32) m += " the CDF walk ended on a masked action (ap[a] > 0.0 would fail in the reference; strict sampling);";
         ppo_set_error(m);
         return PPO_ERR_DEVICE_FLAG;
     }

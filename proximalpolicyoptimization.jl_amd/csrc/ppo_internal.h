@@ -57,6 +57,7 @@ struct DevBuf {
 // ---------------------------------------------------------------- handles
 struct ppo_env_s {
     int32_t kind, Q, H, A, V, F, max_actions;
+    int32_t strict_sampling = 0;       // 1: a CDF residue landing on a masked action is an error (reference @assert)
     float no_action_reward;
     int64_t N, global_offset;
     uint64_t seed;

@@ -286,6 +286,9 @@ def test_cdf_residue_goes_to_last_unmasked_action(P, orc):
             probs = ro.full_probs()[t, 1]
             if env.error_flags() & 32:
                 fired += 1
+                strict = P.HipVecEnv(num_envs=N, Q=8, max_actions=20, seed=seed, global_offset=gid - 1, strict_sampling=True)
+                with pytest.raises(P.PPOError, match="ap\\[a\\] > 0.0"):       # reference semantics on request
+                    P.collect_rollouts_steps_(P.BufferRollouts(), strict, pol, T, 1.0)
                 a = int(ro.selected_actions[t, 1]) - 1
                 assert a == int(np.nonzero(probs > 0)[0].max()) and oenv.err[1] & 32
                 csum = np.float32(0)
