@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 N_ENVS, T_STEPS, HID, F, EPOCHS, MINIBATCH = 4096, 128, 256, 72, 4, 4096
+QUADS = 8                             # quad slots per env: H = 4*QUADS half-edge rows, A = 16*QUADS actions
 GAMMA, EPS, ENT_W, LR = 1.0, 0.05, 0.01, 1e-4
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--dtype bf16 runs only)
@@ -31,11 +32,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF 
 
 def flops_per_state(kind):
     """Algorithmic flops of one 32-row state tile on the matrix pipe (DESIGN.md 'Kernels')."""
-    fwd = 2 * 32 * (F * HID + HID * HID + HID * 4)
+    rows = 4 * QUADS                     # half-edge rows of one state (32 for the headline workload)
+    fwd = 2 * rows * (F * HID + HID * HID + HID * 4)
     if kind == "fwd":
         return fwd
     # backward: dH1 = W2^T dZ2 (HID*HID), dW2 (HID*HID), dW1 (HID*F), dW3/dH2 (2*HID*4)
-    return 2 * 32 * (2 * HID * HID + HID * F + 2 * HID * 4)
+    return 2 * rows * (2 * HID * HID + HID * F + 2 * HID * 4)
 
 
 def cpu_baseline():
@@ -70,7 +72,7 @@ def cpu_baseline():
 
 
 def main():
-    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH
+    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -82,13 +84,17 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline line); bf16 = the config-5 arithmetic on the same workload "
                          "(flagged in the output, not the headline)")
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default 4096 = the headline workload)")
+    ap.add_argument("--quads", type=int, choices=[8, 32], default=QUADS,
+                    help="quad slots per env: 8 = the headline rand-poly shape (A=128), 32 = the square-mesh-sized action "
+                         "space of BASELINE config 4 (A=512, variable-length masked episodes; flagged in the output)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, BASELINE config 3): 4096 envs and a 4096-sample minibatch PER GPU; strong: the 4096 envs "
                          "and the 4096-sample global minibatch are split over the GPUs (flagged in the output)")
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
-    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak")
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS)
+    QUADS = args.quads
     N_ENVS = MINIBATCH = args.envs
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +128,7 @@ def main():
         PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     dp = PPO.DataParallel(rank, world, force_hook=use_dist)
-    env = PPO.HipVecEnv(num_envs=N_ENVS, Q=8, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
+    env = PPO.HipVecEnv(num_envs=N_ENVS, Q=QUADS, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
     pol = PPO.HipPolicy(F, HID, 2, 4, seed=0, dtype=args.dtype)
     opt = PPO.Optimiser(PPO.Adam(LR))
     ro = PPO.BufferRollouts()
@@ -200,7 +206,7 @@ def main():
                     "vector instruction between MFMAs adds ~2 ns per SIMD: instruction-mix ceiling of this kernel "
                     "(2432 MFMA + ~5250 vector instr per tile) ~125-130 TFLOP/s",
                     "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
-                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (2 * HID * 32 * 4 + 32 * F + 32 * 16) + 256 * 4 *
+                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (QUADS // 8) * (2 * HID * 32 * 4 + 32 * F + 32 * 16) + 256 * 4 *
                     (HID * HID + HID * 96 + HID * 6 + 4)}
     elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
@@ -213,10 +219,10 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=8,H=32,A=128,F=72 int8), "
+            "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=%d,H=%d,A=%d,F=72 int8), "
                                    "2x256 MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
                                    "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)"
-                                   % (N_ENVS, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
+                                   % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world},
