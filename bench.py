@@ -183,6 +183,11 @@ def main():
         gbs = 9.0 * 128 * 65536 / (ms * 1e-3) / 1e9
         kernels["k_returns_tn@65536x128"] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
                                              "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
+        # the same scan on 4x the columns: at the config-5 size a 20 us launch is half ramp-up (75 MB over 256 CUs)
+        ms = PPO.profile_returns(128, 262144, GAMMA, 10)
+        gbs = 9.0 * 128 * 262144 / (ms * 1e-3) / 1e9
+        kernels["k_returns_tn@262144x128"] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
+                                              "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
         k = kernels.get("k_policy_bwd")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
