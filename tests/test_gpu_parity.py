@@ -708,3 +708,19 @@ def test_ppo_iterate_disk_method(P, tmp_path):
     assert len(calls) == 2 and len(loss["ppo"]) == 2 and not os.path.exists(path)
     loss2 = P.ppo_iterate_(pol, env, opt, 8, 8, 1, lambda p, e, o: None, 2, 1.0, 0.05, 0.01, verbose=False)
     assert len(loss2["entropy"]) == 2 and loss2["lr"] == [1e-4, 1e-4]
+
+
+def test_example_driver_script_learns_and_checkpoints(P, tmp_path, monkeypatch):
+    """examples/train_rand_poly.py: the reference's driver-script shape (evaluator object + save_loss plugin +
+    ppo_iterate! + BSON checkpoint of the best policy) runs end to end and improves the average return."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_rand_poly", os.path.join(root, "examples", "train_rand_poly.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "best.bson")
+    monkeypatch.setattr(sys, "argv", ["train_rand_poly.py", "--iterations", "6", "--envs", "256", "--out", out])
+    ev = mod.main()
+    assert os.path.exists(out) and ev.loss is not None and len(ev.loss["ppo"]) == 6 * 4
+    assert ev.best_return > ev.mean_returns[0] + 1.0, ev.mean_returns
