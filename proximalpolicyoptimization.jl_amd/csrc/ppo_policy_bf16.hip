@@ -683,6 +683,8 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     // dW1 kernel live in their upper halves (z1f behind act1b, xf behind act2b; NI <= NT)
     a.z1f = (uint4*)p->act1.p + (size_t)a.B * (p->HID / 32) * 128;
     a.xf = (uint4*)p->act2.p + (size_t)a.B * (p->HID / 32) * 128;
+    ARG_CHECK(p->act1.n >= (size_t)a.B * (p->HID / 32) * 1024 && p->act2.n >= (size_t)a.B * (p->HID / 32) * 1024,
+              "bf16 backward: activation workspace smaller than the minibatch (train_reserve)");
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
     a.stamps = nullptr;
 #ifdef PPO_BF16_STAMP
