@@ -2,6 +2,7 @@
 // the host-side orchestration of collect_rollouts! / ppo_train! (launch order only; all math is
 // in the kernels).  There is NO CPU fallback: every entry point runs on the GPU or fails.
 #include "ppo_internal.h"
+#include "ppo_device.h"
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -237,7 +238,14 @@ int32_t ppo_env_create(int32_t kind, int64_t num_envs, int64_t global_env_offset
     if ((s = e->score.alloc(N * e->V)) || (s = e->degree.alloc(N * e->V)) || (s = e->active.alloc(N)) ||
         (s = e->steps.alloc(N)) || (s = e->reward.alloc(N)) || (s = e->done.alloc(N)) || (s = e->episode.alloc(N)) ||
         (s = e->tick.alloc(N)) || (s = e->err.alloc(1)) || (s = e->actions_tmp.alloc(N)) ||
-        (s = e->episodes_left.alloc(N))) { delete e; return s; }
+        (s = e->episodes_left.alloc(N)) || (s = e->tmpl.alloc((size_t)e->H * PPO_TPL))) { delete e; return s; }
+    {   // the observation template depends on (half-edge, template row) only: tabulated once (1-4.5 KB, cache resident)
+        std::vector<int8_t> t((size_t)e->H * PPO_TPL);
+        for (int h = 0; h < e->H; ++h)
+            for (int k = 0; k < PPO_TPL; ++k) t[(size_t)h * PPO_TPL + k] = (int8_t)env_template(Q, h, k);
+        s = h2d(e->tmpl.p, t.data(), t.size());
+        if (s) { delete e; return s; }
+    }
     (void)hipMemsetAsync(e->episode.p, 0, N * 4, g_stream);
     (void)hipMemsetAsync(e->tick.p, 0, N * 4, g_stream);
     (void)hipMemsetAsync(e->err.p, 0, 4, g_stream);

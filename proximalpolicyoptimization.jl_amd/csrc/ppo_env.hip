@@ -8,7 +8,7 @@
 
 struct EnvView {
     int8_t* score; int8_t* degree; uint32_t* active; int32_t* steps; float* reward; uint8_t* done;
-    uint32_t* episode; uint32_t* tick; int32_t* err; int32_t* episodes_left;
+    uint32_t* episode; uint32_t* tick; int32_t* err; int32_t* episodes_left; const int8_t* tmpl;
     int32_t Q, V, max_actions; float no_action_reward; int64_t N, global_offset; uint32_t k0, k1;
 };
 
@@ -16,7 +16,7 @@ static EnvView view_of(ppo_env_s* e) {
     EnvView v;
     v.score = e->score.p; v.degree = e->degree.p; v.active = e->active.p; v.steps = e->steps.p;
     v.reward = e->reward.p; v.done = e->done.p; v.episode = e->episode.p; v.tick = e->tick.p; v.err = e->err.p;
-    v.episodes_left = e->episodes_left.p;
+    v.episodes_left = e->episodes_left.p; v.tmpl = e->tmpl.p;
     v.Q = e->Q; v.V = e->V; v.max_actions = e->max_actions; v.no_action_reward = e->no_action_reward;
     v.N = e->N; v.global_offset = e->global_offset; v.k0 = (uint32_t)e->seed; v.k1 = (uint32_t)(e->seed >> 32);
     return v;
@@ -166,10 +166,12 @@ __global__ void k_env_observe(EnvView e, int8_t* __restrict__ obs, uint32_t* __r
     const int8_t* src = (f0 < PPO_TPL) ? (e.score + n * V) : (e.degree + n * V);
     const int t0 = (f0 < PPO_TPL) ? f0 : f0 - PPO_TPL;
     const bool own = (act >> (h >> 2)) & 1u;
+    // four template vertex ids at once from the [H][36] table (36 % 4 == 0, t0 % 4 == 0: one aligned dword)
+    const uint32_t ids = *reinterpret_cast<const uint32_t*>(e.tmpl + h * PPO_TPL + t0);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int v = env_template(e.Q, h, t0 + i);
+        const int v = (int)(int8_t)(ids >> (8 * i));
         const bool ok = own && v >= 0 && ((act >> (v >> 2)) & 1u);
         const int8_t val = ok ? src[v] : (int8_t)0;
         packed |= ((uint32_t)(uint8_t)val) << (8 * i);

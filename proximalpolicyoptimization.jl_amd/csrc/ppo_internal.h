@@ -71,6 +71,7 @@ struct ppo_env_s {
     DevBuf<int32_t> actions_tmp;       // [N]
     DevBuf<int8_t> obs_tmp;            // [N][H][F]
     DevBuf<int32_t> episodes_left;     // [N] (episodes mode)
+    DevBuf<int8_t> tmpl;               // [H][36] template vertex ids (env_template), -1 = missing: looked up by k_env_observe
 };
 
 struct ppo_policy_s {
