@@ -3,8 +3,7 @@
 // QuadMeshGame's dynamics are not in the reference tree, so this is an honest synthetic stand-in
 // with exactly specified integer dynamics (DESIGN.md "Synthetic env"): SoA state in HBM, one
 // thread per env for the integer update, one thread per output dword for the observation.
-#include "ppo_internal.h"
-#include "ppo_device.h"
+#include "ppo_env_device.h"
 
 struct EnvView {
     int8_t* score; int8_t* degree; uint32_t* active; int32_t* steps; float* reward; uint8_t* done;
@@ -22,28 +21,19 @@ static EnvView view_of(ppo_env_s* e) {
     return v;
 }
 
+static __device__ __forceinline__ EnvConst const_of(const EnvView& e) {
+    EnvConst c;
+    c.Q = e.Q; c.V = e.V; c.max_actions = e.max_actions; c.no_action_reward = e.no_action_reward; c.k0 = e.k0; c.k1 = e.k1;
+    return c;
+}
+static __device__ __forceinline__ EnvRef ref_of(const EnvView& e, int64_t n) {
+    EnvRef r;
+    r.sc = e.score + n * e.V; r.dg = e.degree + n * e.V; r.active = e.active + n; r.steps = e.steps + n;
+    r.reward = e.reward + n; r.done = e.done + n; r.episode = e.episode + n; r.tick = e.tick + n;
+    return r;
+}
 __device__ __forceinline__ void env_reset_one(const EnvView& e, int64_t n) {
-    const int V = e.V, Q = e.Q, nact = (3 * Q) / 4;
-    int8_t* sc = e.score + n * V;
-    int8_t* dg = e.degree + n * V;
-    const uint32_t g = (uint32_t)(e.global_offset + n);
-    const uint32_t ep = e.episode[n];
-    for (int q = 0; q < Q; ++q) {
-        uint32_t w[4];
-        philox4x32_10(g, ep, 1u, (uint32_t)q, e.k0, e.k1, w);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = 4 * q + i;
-            if (q < nact) {
-                const int s = (int)(w[i] % 5u) - 2;
-                const int desired = 3 + (int)((w[i] >> 8) & 1u);
-                sc[v] = (int8_t)s; dg[v] = (int8_t)(desired - s);
-            } else { sc[v] = 0; dg[v] = 0; }
-        }
-    }
-    e.active[n] = (nact >= 32) ? 0xFFFFFFFFu : ((1u << nact) - 1u);
-    e.steps[n] = 0; e.reward[n] = 0.0f; e.done[n] = 0;
-    e.episode[n] = ep + 1u;
+    env_reset_ref(const_of(e), ref_of(e, n), (uint32_t)(e.global_offset + n));
 }
 
 __global__ void k_env_reset(EnvView e, int only_done) {
@@ -51,21 +41,6 @@ __global__ void k_env_reset(EnvView e, int only_done) {
     if (n >= e.N) return;
     if (only_done && !e.done[n]) return;
     env_reset_one(e, n);
-}
-
-__device__ __forceinline__ bool deg_ok(int d) { return d >= 2 && d <= 7; }
-
-__device__ __forceinline__ int total_abs(const int8_t* sc, uint32_t act, int Q) {
-    int s = 0;
-    for (int q = 0; q < Q; ++q) if ((act >> q) & 1u)
-        for (int i = 0; i < 4; ++i) { int x = sc[4 * q + i]; s += x < 0 ? -x : x; }
-    return s;
-}
-__device__ __forceinline__ int total_sum(const int8_t* sc, uint32_t act, int Q) {
-    int s = 0;
-    for (int q = 0; q < Q; ++q) if ((act >> q) & 1u)
-        for (int i = 0; i < 4; ++i) s += sc[4 * q + i];
-    return s;
 }
 
 // step!(env, a) for every env + record reward/is_terminal + optional auto-reset
@@ -81,61 +56,10 @@ __global__ void k_env_step(EnvView e, const int32_t* __restrict__ actions, float
         if (done_out) done_out[n] = 1;
         return;
     }
-    const int V = e.V, Q = e.Q, A = 16 * Q;
-    int8_t* sc = e.score + n * V;
-    int8_t* dg = e.degree + n * V;
-    uint32_t act = e.active[n];
-    int errf = 0;
-    e.tick[n] += 1u;
-    int a = actions[n];
-    if (e.done[n]) { atomicOr(e.err, 4); return; }
-    if (a < 0 || a >= A) { errf |= 2; a = 0; }
-    const int q = a / 16, ed = (a % 16) / 4, type = a % 4;
-    const int old_total = total_abs(sc, act, Q);
-    bool valid = false;
-    if (!((act >> q) & 1u)) {
-        errf |= 1;
-    } else {
-        const int v0 = 4 * q + ed, v1 = 4 * q + ((ed + 1) & 3), v2 = 4 * q + ((ed + 2) & 3), v3 = 4 * q + ((ed + 3) & 3);
-        const int nq = (q + 1 + ed) % Q;
-        const int w0 = 4 * nq + ed, w1 = 4 * nq + ((ed + 1) & 3);
-        const bool nq_ok = (nq != q) && ((act >> nq) & 1u);
-        if (type == 0 || type == 1) {
-            const int p = (type == 0) ? v3 : v2, r = (type == 0) ? w0 : w1;
-            if (nq_ok && deg_ok(dg[v0] - 1) && deg_ok(dg[v1] - 1) && deg_ok(dg[p] + 1) && deg_ok(dg[r] + 1)) {
-                dg[v0]--; sc[v0]++; dg[v1]--; sc[v1]++;
-                dg[p]++; sc[p]--; dg[r]++; sc[r]--;
-                valid = true;
-            }
-        } else if (type == 2) {
-            int f = -1;
-            for (int s = 0; s < Q; ++s) if (!((act >> s) & 1u)) { f = s; break; }
-            if (f >= 0 && deg_ok(dg[v0] + 1) && deg_ok(dg[v2] + 1)) {
-                dg[v0]++; sc[v0]--; dg[v2]++; sc[v2]--;
-                for (int i = 0; i < 4; ++i) { sc[4 * f + i] = 0; dg[4 * f + i] = 4; }
-                act |= (1u << f);
-                valid = true;
-            }
-        } else {
-            const int cnt = __popc(act);
-            if (nq_ok && cnt > Q / 2 && deg_ok(dg[w0] - 1) && deg_ok(dg[w1] - 1)) {
-                dg[w0]--; sc[w0]++; dg[w1]--; sc[w1]++;
-                for (int i = 0; i < 4; ++i) { sc[4 * q + i] = 0; dg[4 * q + i] = 0; }
-                act &= ~(1u << q);
-                valid = true;
-            }
-        }
-    }
+    float rew; uint8_t dn;
+    const int errf = env_step_ref(const_of(e), ref_of(e, n), actions[n], rew, dn);
     if (errf) atomicOr(e.err, errf);
-    e.active[n] = act;
-    const int new_total = total_abs(sc, act, Q);
-    const float rew = valid ? (float)(old_total - new_total) : e.no_action_reward;
-    const int st = e.steps[n] + 1;
-    e.steps[n] = st;
-    const int sum = total_sum(sc, act, Q);
-    const int opt = sum < 0 ? -sum : sum;
-    const uint8_t dn = (uint8_t)((new_total == opt) || (st >= e.max_actions));
-    e.reward[n] = rew; e.done[n] = dn;
+    if (errf & 4) return;                          // step! on a terminated env: nothing recorded (as before)
     if (reward_out) reward_out[n] = rew;
     if (done_out) done_out[n] = dn;
     if (valid_out) valid_out[n] = 1;
