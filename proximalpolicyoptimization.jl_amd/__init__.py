@@ -89,6 +89,12 @@ def device_count():
     return _lib.device_count()
 
 
+def set_rollout_persistent(on=True):
+    """One launch per rollout (each wavefront walks its envs through all T steps) instead of three launches per step.
+    Bit-identical results; default off (measured equal at 4096 envs)."""
+    call("ppo_set_rollout_persistent", int(bool(on)))
+
+
 def synchronize():
     call("ppo_device_synchronize")
 

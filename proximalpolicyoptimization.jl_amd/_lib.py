@@ -45,6 +45,7 @@ SIGNATURES = {
     "ppo_env_get_reward": [H, c_f32p],
     "ppo_env_get_terminal": [H, c_u8p],
     "ppo_env_get_internal": [H, c_i8p, c_i8p, c_i32p, c_u32p, c_u32p],
+    "ppo_set_rollout_persistent": [C.c_int32],
     "ppo_env_check_errors": [H, c_i32p],
     "ppo_env_set_strict_sampling": [H, C.c_int32],
     "ppo_policy_create": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, HP],

@@ -158,6 +158,7 @@ int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uin
 int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
                               int32_t* actions_out, float* psel_out, float* full_probs_or_null);
 // adv_col: the advantage column indexed by transition id (ro->returns for PPO_ADV_RETURNS)
+int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs);
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                 int64_t B_global, double eps, double entropy_weight, const float* adv_col);
 int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col);

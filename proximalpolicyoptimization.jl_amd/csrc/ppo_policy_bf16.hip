@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l[tt][i] = (tt == ts) ? lg[i] : l[tt][i];
         }
-        policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h);
+        policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, (MODE == 1) ? a.tick[state] : 0u, state);
     }
 }
 

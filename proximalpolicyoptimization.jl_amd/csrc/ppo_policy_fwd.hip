@@ -17,6 +17,7 @@
 // MFMA-bound: 2*(F*HID + HID*HID)*32 flop per state on the matrix pipe; layer 3 (HID x 4) is a VALU
 // dot-product epilogue.
 #include "ppo_policy_tail.h"
+#include "ppo_env_device.h"
 
 // activation stores of the train forward: tuning knobs for A/B builds (defaults are the shipped configuration)
 #ifndef PPO_FWD_STORE
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 
     // the rows of the NEXT 32-row tile are fetched while the current one computes (the gather through idx is two
     // dependent HBM round trips that one wave per SIMD cannot hide otherwise)
-    constexpr bool PFX = (FwdCfg<F, HID>::WPS == 1);    // with two waves per SIMD the partner wave hides it instead
+    constexpr bool PFX = (FwdCfg<F, HID>::WPS == 1) && MODE != 3;   // with two waves per SIMD the partner wave hides it instead;
+                                                                  // MODE 3 computes the rows itself (no fetch)
     uint32_t xw[XW];
     auto fetch_rows = [&](int64_t state, int ts) {
         const int64_t sidn = (MODE == 2) ? (int64_t)a.idx[state] : state;
@@ -95,9 +97,45 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
-    for (int64_t state = wave; state < a.B; state += nwaves) {
+    // ---- MODE 3: persistent rollout.  Envs are independent, so every wave walks ITS envs (state = wave, wave + nwaves,
+    // ...) through all T steps without any grid-wide synchronisation: observe -> MLP -> sample -> step!, with the env
+    // state (scores, degrees, counters) resident in the wave's LDS slots and written back once at the end.
+    extern __shared__ __attribute__((aligned(16))) char env_lds[];
+    const int slot_bytes = 2 * a.envV + 32;
+    char* const my_slots = env_lds + (size_t)(threadIdx.x >> 6) * a.env_slots * slot_bytes;
+    EnvConst ec;
+    auto slot_ref = [&](int slot) {
+        char* b = my_slots + (size_t)slot * slot_bytes;
+        EnvRef r;
+        r.sc = reinterpret_cast<int8_t*>(b); r.dg = r.sc + a.envV;
+        uint32_t* w = reinterpret_cast<uint32_t*>(b + 2 * a.envV);
+        r.active = w; r.steps = reinterpret_cast<int32_t*>(w + 1); r.reward = reinterpret_cast<float*>(w + 2);
+        r.done = reinterpret_cast<uint8_t*>(w + 3); r.episode = w + 4; r.tick = w + 5;
+        return r;
+    };
+    if (MODE == 3) {
+        ec.Q = a.envQ; ec.V = a.envV; ec.max_actions = a.env_max_actions; ec.no_action_reward = a.env_nar; ec.k0 = a.k0; ec.k1 = a.k1;
+        int slot = 0;
+        for (int64_t n = wave; n < a.B; n += nwaves, ++slot) {
+            const EnvRef r = slot_ref(slot);
+            for (int v = lane; v < a.envV; v += 64) { r.sc[v] = a.env_score[n * a.envV + v]; r.dg[v] = a.env_degree[n * a.envV + v]; }
+            if (lane == 0) {
+                *r.active = a.env_active[n]; *r.steps = a.env_steps[n]; *r.reward = a.env_reward[n];
+                *reinterpret_cast<uint32_t*>(r.done) = a.env_done[n]; *r.episode = a.env_episode[n]; *r.tick = a.env_tick[n];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slots are wave-private: program order + in-order LDS suffice
+    }
+    const int64_t t_steps = (MODE == 3) ? a.T : 1;
+    for (int64_t tt = 0; tt < t_steps; ++tt) {
+    int slot = 0;
+    for (int64_t state = wave; state < a.B; state += nwaves, ++slot) {
         const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
-        const uint32_t act = a.active[sid];
+        EnvRef er;
+        if (MODE == 3) er = slot_ref(slot);
+        const uint32_t act = (MODE == 3) ? *er.active : a.active[sid];
+        const uint32_t tick_val = (MODE == 3) ? *er.tick : ((MODE == 1) ? a.tick[state] : 0u);
+        const int64_t out_index = (MODE == 3) ? tt * a.B + state : state;
         float l[TPS][4];
         // multi-tile states: the tile loop stays a real loop (no 4x code blow-up, no cross-tile hoisting that
         // would spill); the 4 logits per lane of each tile are parked in LDS and re-read after the loop
@@ -111,7 +149,16 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             int lane_o = lane, half_o = h;
             asm volatile("" : "+v"(lane_o), "+v"(half_o));
             // ---- state rows -> B operands of layer 1: lane half 0 holds features [0,F/2), half 1 [F/2,F)
-            if (!PFX) fetch_rows(state, ts);
+            if (MODE == 3) {
+                // state(env): this lane's 36 features of half-edge row 32*ts + j, recorded into the rollout buffer
+                static_assert(MODE != 3 || XW == 9, "the built-in env has F = 72 features");
+                uint32_t ob[9];
+                env_observe_lane(er, a.env_tmpl + (32 * ts + j) * PPO_TPL, 32 * ts + j, h, ob);
+                uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + ((size_t)out_index * TPS + ts) * 32 * F +
+                                                           (size_t)j * F + (size_t)h * XB);
+#pragma unroll
+                for (int k = 0; k < XW; ++k) { xw[k] = ob[k < 9 ? k : 0]; so[k] = xw[k]; }
+            } else if (!PFX) fetch_rows(state, ts);
             float xf[XB];
 #pragma unroll
             for (int k = 0; k < XW; ++k) {
@@ -238,8 +285,34 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
         }
 
         FSTAMP(4);
-        policy_tail<MODE, TPS, false>(a, state, sid, act, l, lane, j, h);
+        const int sampled = policy_tail<MODE, TPS, false>(a, state, sid, act, l, lane, j, h, tick_val, out_index);
+        if (MODE == 3) {
+            // update!: the observed mask, then step!(env, a), reward, is_terminal (src/collect_rollouts.jl:9-14) and the
+            // reset! before the next episode (src/rollout_buffer.jl:75) -- one lane, on the LDS slot
+            asm volatile("" ::: "memory");
+            if (lane == 0) {
+                a.active_out[out_index] = act;
+                float rew; uint8_t dn;
+                const int errf = env_step_ref(ec, er, sampled, rew, dn);
+                if (errf) atomicOr(a.err, errf);
+                a.rew_out[out_index] = rew; a.done_out[out_index] = dn;
+                if (dn) env_reset_ref(ec, er, (uint32_t)(a.global_offset + state));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         FSTAMP(5);
+    }
+    }
+    if (MODE == 3) {                                            // env state back to the [N] arrays
+        int slot2 = 0;
+        for (int64_t n = wave; n < a.B; n += nwaves, ++slot2) {
+            const EnvRef r = slot_ref(slot2);
+            for (int v = lane; v < a.envV; v += 64) { a.env_score[n * a.envV + v] = r.sc[v]; a.env_degree[n * a.envV + v] = r.dg[v]; }
+            if (lane == 0) {
+                a.env_active[n] = *r.active; a.env_steps[n] = *r.steps; a.env_reward[n] = *r.reward;
+                a.env_done[n] = *r.done; a.env_episode[n] = *r.episode; a.env_tick[n] = *r.tick;
+            }
+        }
     }
 #ifdef PPO_FWD_STAMP
     if (a.stamps && lane == 0 && wave < 1024)
@@ -325,6 +398,51 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
     ProfScope ps("k_policy_fwd_rollout");
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 1, e->N, e->H / 32);
     return dispatch_fwd<1>(p, a, e->N, e->H / 32);
+}
+
+// Persistent rollout (MODE 3): T steps of all N envs in one launch.  Returns PPO_ERR_UNSUPPORTED (without setting an
+// error) when the shape is not covered, so the caller falls back to the per-step launches.
+int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs) {
+    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || e->F != 72) return PPO_ERR_UNSUPPORTED;
+    const int tps = e->H / 32;
+    const int64_t N = e->N;
+    const int64_t need = (N + 3) / 4;
+    const int wps = (p->HID >= 256) ? 1 : 2;                     // FwdCfg<72, HID>::WPS
+    const int64_t cap = 256 * wps;
+    const unsigned grid = (unsigned)(need < cap ? need : cap);
+    const int slots = (int)((N + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4));
+    const size_t lds = (size_t)4 * slots * (2 * e->V + 32);
+    if (lds > 96 * 1024) return PPO_ERR_UNSUPPORTED;
+    FwdArgs a = {};
+    fill_weights(p, a);
+    a.B = N; a.T = T;
+    a.global_offset = e->global_offset; a.k0 = (uint32_t)e->seed; a.k1 = (uint32_t)(e->seed >> 32);
+    a.env_score = e->score.p; a.env_degree = e->degree.p; a.env_active = e->active.p; a.env_steps = e->steps.p;
+    a.env_reward = e->reward.p; a.env_done = e->done.p; a.env_episode = e->episode.p; a.env_tick = e->tick.p;
+    a.env_tmpl = e->tmpl.p; a.envQ = e->Q; a.envV = e->V; a.env_max_actions = e->max_actions; a.env_slots = slots;
+    a.env_nar = e->no_action_reward; a.err = e->err.p;
+    a.states_out = ro->states.p; a.active_out = ro->active.p; a.actions_out = ro->actions.p; a.psel_out = ro->p_sel.p;
+    a.rew_out = ro->rewards.p; a.done_out = ro->done.p;
+    a.full_probs = record_probs ? ro->full_probs.p : nullptr;
+    ProfScope ps("k_rollout_persistent");
+#define LAUNCH3(HH, TT)                                                                                      \
+    do {                                                                                                     \
+        static size_t attr_lds = 0;                                                                          \
+        if (lds > attr_lds) {                                                                                \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd<72, HH, 3, TT>,                            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+            attr_lds = lds;                                                                                  \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_policy_fwd<72, HH, 3, TT>), dim3(grid), dim3(256), lds, ppo_stream(), a);      \
+    } while (0)
+    if (p->HID == 256 && tps == 1) LAUNCH3(256, 1);
+    else if (p->HID == 256 && tps == 4) LAUNCH3(256, 4);
+    else if (p->HID == 128 && tps == 1) LAUNCH3(128, 1);
+    else if (p->HID == 128 && tps == 4) LAUNCH3(128, 4);
+    else return PPO_ERR_UNSUPPORTED;
+#undef LAUNCH3
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
 }
 
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,

@@ -24,6 +24,12 @@ struct FwdArgs {
     float4* act1; float4* act2; float4* dY; double* loss_terms;
     const int32_t* actions; const float* p_old; const float* adv;
     double eps; float c_over_B; float inv_B;
+    // MODE 3 (persistent rollout: T steps of every env in ONE launch; env state lives in the wave's LDS slots)
+    int64_t T;                                                   // steps
+    int8_t* env_score; int8_t* env_degree; uint32_t* env_active; int32_t* env_steps; float* env_reward;
+    uint8_t* env_done; uint32_t* env_episode; uint32_t* env_tick; const int8_t* env_tmpl;
+    int32_t envQ, envV, env_max_actions, env_slots; float env_nar;
+    int8_t* states_out; uint32_t* active_out; float* rew_out; uint8_t* done_out;      // rollout columns [T][N]
     // bf16 compute mode (ppo_policy_bf16.hip): bf16 fragment streams and bf16 saved activations
     const uint4* w1b; const uint4* w2b; const uint4* w3c; uint4* act1b; uint4* act2b;
 };
@@ -51,9 +57,13 @@ __device__ __forceinline__ float dy_round(float x) {
 }
 
 // l[ts][i]: logit of action 128*ts + 4*j + i of the state, present in both lane halves (j = lane & 31).
+// MODE 1 / 3 (rollout): tick_val = the env's tick (Philox counter word), out_index = position of the transition in
+// the output columns (state for one step, t*N + state for the persistent rollout); returns the sampled action.
 template <int MODE, int TPS, bool DYBF16>
-__device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t state, const int64_t sid, const uint32_t act,
-                                            float (&l)[TPS][4], const int lane, const int j, const int h) {
+__device__ __forceinline__ int policy_tail(const FwdArgs& a, const int64_t state, const int64_t sid, const uint32_t act,
+                                           float (&l)[TPS][4], const int lane, const int j, const int h,
+                                           const uint32_t tick_val = 0u, const int64_t out_index = 0) {
+    int sampled = 0;
     constexpr int A = 128 * TPS;
     // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
     bool on[TPS];
@@ -87,10 +97,10 @@ __device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t stat
                     make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
         }
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         // rand(Categorical(p)): sequential fp32 inverse-CDF walk, same uniform as the oracle
         uint32_t rnd[4];
-        philox4x32_10((uint32_t)(a.global_offset + state), a.tick[state], 0u, 0u, a.k0, a.k1, rnd);
+        philox4x32_10((uint32_t)(a.global_offset + state), tick_val, 0u, 0u, a.k0, a.k1, rnd);
         const float u = u01_from_u32(rnd[0]);
         float cp = readlane_f(p[0][0], 0);
         int ia = 0;
@@ -133,13 +143,14 @@ __device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t stat
             if (lane == 0) atomicOr(a.err, best >= 0 ? 32 : 8);
         }
         if (lane == 0) {
-            a.actions_out[state] = ia;
-            a.psel_out[state] = psel;
+            a.actions_out[out_index] = ia;
+            a.psel_out[out_index] = psel;
         }
+        sampled = ia;
         if (a.full_probs && h == 0) {
 #pragma unroll
             for (int ts = 0; ts < TPS; ++ts)
-                reinterpret_cast<float4*>(a.full_probs)[((size_t)state * TPS + ts) * 32 + j] =
+                reinterpret_cast<float4*>(a.full_probs)[((size_t)out_index * TPS + ts) * 32 + j] =
                     make_float4(p[ts][0], p[ts][1], p[ts][2], p[ts][3]);
         }
     }
@@ -183,4 +194,5 @@ __device__ __forceinline__ void policy_tail(const FwdArgs& a, const int64_t stat
         }
         if (lane == 0) { a.loss_terms[state * 2] = minval; a.loss_terms[state * 2 + 1] = (double)(-hl); }
     }
+    return sampled;
 }

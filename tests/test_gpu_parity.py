@@ -196,7 +196,7 @@ def test_policy_forward(P, orc, golden_dir, F, HID, fixture):
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
 @pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10)])
-def test_rollout_bitexact(P, orc, N, T, HID, max_actions):
+def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode):
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=max_actions, seed=77, global_offset=5)
     pol = P.HipPolicy(72, HID, 2, 4, seed=11)
     ro = P.BufferRollouts()
@@ -220,8 +220,16 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions):
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
 
 
+@pytest.fixture(params=[False, True], ids=["per-step", "persistent"])
+def rollout_mode(request, P):
+    """Both rollout executions: three launches per step, and the whole T-step rollout in one launch (MODE 3)."""
+    P.set_rollout_persistent(request.param)
+    yield request.param
+    P.set_rollout_persistent(False)
+
+
 @pytest.mark.parametrize("case", range(10))
-def test_rollout_bitexact_fuzz(P, orc, case):
+def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode):
     """Randomised shapes / seeds / horizons / global offsets: whole rollouts stay bit-identical to the device-order
     oracle (states, masks, sampled actions, probabilities, rewards, done flags, returns in both discount types)."""
     rng = np.random.default_rng(1000 + case)
@@ -263,7 +271,7 @@ def test_gradient_ragged_batch_sizes(P, orc, B):
     assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
 
 
-def test_cdf_residue_goes_to_last_unmasked_action(P, orc):
+def test_cdf_residue_goes_to_last_unmasked_action(P, orc, rollout_mode):
     """u = 1 - 2^-24 (the largest uniform) against a distribution whose sequential fp32 sum stops at or below it: the
     walk runs off the end onto a masked action (p = 0), where the reference's `@assert ap[a] > 0.0` would throw
     (src/collect_rollouts.jl:7).  The engine and the oracle give the residue to the last action with p > 0 (flag 32).
@@ -545,7 +553,7 @@ def test_policy_forward_q32(P, orc):
 
 
 @pytest.mark.parametrize("HID", [128, 256])
-def test_rollout_and_gradient_q32(P, orc, HID):
+def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode):
     """square_mesh-sized action space (Q=32 quads, 512 masked actions), variable-length episodes."""
     N, T, max_actions = 12, 20, 9
     env = P.HipVecEnv(num_envs=N, Q=32, max_actions=max_actions, seed=31)
