@@ -165,8 +165,9 @@ def main():
         PPO.profile_enable(True)
         iteration(args.warmup + args.steps)
         PPO.synchronize()
-        # k_rollout_persistent: the whole rollout (T steps of every env: observe + MLP + sample + step!) in one launch;
-        # k_policy_fwd_rollout is the per-step form (bf16 mode, disk streaming, PPO_ROLLOUT_PERSISTENT=0)
+        # k_rollout_persistent: the whole rollout (T steps of every env: observe + MLP + sample + step!) in one launch
+        # (the default for Q = 8 in fp32 mode); k_policy_fwd_rollout is the per-step form (bf16 mode, Q = 32, disk
+        # streaming, PPO_ROLLOUT_PERSISTENT=0)
         for name, kind, per in [("k_policy_bwd", "bwd", MINIBATCH), ("k_policy_fwd_train", "fwd", MINIBATCH),
                                 ("k_policy_fwd_rollout", "fwd", N_ENVS), ("k_rollout_persistent", "fwd", N_ENVS * T_STEPS)]:
             ms, n = PPO.profile_get(name)

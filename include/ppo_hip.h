@@ -54,10 +54,11 @@ int32_t ppo_device_init(int32_t device_ordinal);          /* hipSetDevice + priv
 int32_t ppo_set_stream(void* hip_stream);                 /* run on an external hipStream_t     */
 int32_t ppo_device_synchronize(void);
 int32_t ppo_device_count(int32_t* out);
-/* rollout execution: 0 (default) = three launches per step (observe, policy forward + sample, step!), 1 = ONE launch
- * for the whole T-step rollout (envs are independent: each wavefront walks its envs through all steps with the env
- * state in LDS).  Same results bit for bit; ignored while a disk sink is attached or for shapes it does not cover. */
-int32_t ppo_set_rollout_persistent(int32_t on);
+/* rollout execution: 0 = three launches per step (observe, policy forward + sample, step!), 1 = ONE launch for the
+ * whole T-step rollout wherever the shape is covered (envs are independent: each wavefront walks its envs through all
+ * steps with the env state in LDS), -1 (default) = automatic: one launch for Q = 8 envs, per-step launches otherwise.
+ * Same results bit for bit; per-step launches are always used while a disk sink is attached. */
+int32_t ppo_set_rollout_persistent(int32_t mode);
 
 /* ---------------------------------------------------------------- standalone ops (parity entry points) */
 /* compute_returns(rewards, terminal, discount)            src/collect_rollouts.jl:26-42

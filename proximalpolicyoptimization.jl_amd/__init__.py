@@ -89,10 +89,11 @@ def device_count():
     return _lib.device_count()
 
 
-def set_rollout_persistent(on=True):
-    """One launch per rollout (each wavefront walks its envs through all T steps) instead of three launches per step.
-    Bit-identical results; default off (measured equal at 4096 envs)."""
-    call("ppo_set_rollout_persistent", int(bool(on)))
+def set_rollout_persistent(on=None):
+    """Rollout execution: True = one launch per rollout (each wavefront walks its envs through all T steps) wherever
+    covered, False = three launches per step, None = automatic (default: one launch for Q = 8 envs).  Bit-identical
+    results either way."""
+    call("ppo_set_rollout_persistent", -1 if on is None else int(bool(on)))
 
 
 def synchronize():

@@ -266,8 +266,9 @@ int32_t ppo_env_dims(ppo_env_t env, int64_t* N, int32_t* H, int32_t* F, int32_t*
     return PPO_OK;
 }
 
-static bool g_rollout_persistent = [] { const char* v = std::getenv("PPO_ROLLOUT_PERSISTENT"); return v && v[0] == '1'; }();
-int32_t ppo_set_rollout_persistent(int32_t on) { g_rollout_persistent = on != 0; return PPO_OK; }
+// -1 = auto (persistent where it is the faster form: Q = 8, wavefront-parallel env update), 0 = off, 1 = on wherever covered
+static int g_rollout_persistent = [] { const char* v = std::getenv("PPO_ROLLOUT_PERSISTENT"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; }();
+int32_t ppo_set_rollout_persistent(int32_t mode) { g_rollout_persistent = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
 
 int32_t ppo_env_set_strict_sampling(ppo_env_t env, int32_t strict) { ARG_CHECK(env, "null env"); env->strict_sampling = strict ? 1 : 0; return PPO_OK; }
 
@@ -488,11 +489,11 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     if (record_probs) PPO_TRY(ro->full_probs.alloc((size_t)T * N * env->A));
     // an env left terminal by a previous call starts a fresh episode (reset! before each episode)
     PPO_TRY(launch_env_reset(env, 1));
-    // One launch for the whole rollout (every wave walks its envs through all T steps: k_policy_fwd MODE 3) is
-    // available when nothing has to happen between the steps (no per-step disk streaming).  Opt-in
-    // (ppo_set_rollout_persistent / PPO_ROLLOUT_PERSISTENT=1): measured equal to the per-step launches at 4096 envs
-    // (26.9 vs 26.8 ms per 128-step rollout -- the env update on one lane costs what the two small launches did).
-    const bool persistent_ok = g_rollout_persistent;
+    // One launch for the whole rollout (every wave walks its envs through all T steps: k_policy_fwd MODE 3) when nothing
+    // has to happen between the steps (no per-step disk streaming).  Default: on for Q = 8, where the env update is
+    // wavefront-parallel (312.7 vs 314.6 ms per bench iteration, same box); off for Q = 32, whose update still runs on
+    // one lane.  ppo_set_rollout_persistent / PPO_ROLLOUT_PERSISTENT=0|1 override.
+    const bool persistent_ok = g_rollout_persistent == 1 || (g_rollout_persistent < 0 && env->Q == 8);
     int32_t ps = PPO_ERR_UNSUPPORTED;
     if (persistent_ok && !ro->sink) ps = launch_policy_rollout_persistent(pol, env, ro, T, record_probs);
     if (ps != PPO_OK && ps != PPO_ERR_UNSUPPORTED) return ps;

@@ -104,34 +104,40 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     const int slot_bytes = 2 * a.envV + 32;
     char* const my_slots = env_lds + (size_t)(threadIdx.x >> 6) * a.env_slots * slot_bytes;
     EnvConst ec;
-    auto slot_ref = [&](int slot) {
-        char* b = my_slots + (size_t)slot * slot_bytes;
-        EnvRef r;
-        r.sc = reinterpret_cast<int8_t*>(b); r.dg = r.sc + a.envV;
-        uint32_t* w = reinterpret_cast<uint32_t*>(b + 2 * a.envV);
-        r.active = w; r.steps = reinterpret_cast<int32_t*>(w + 1); r.reward = reinterpret_cast<float*>(w + 2);
-        r.done = reinterpret_cast<uint8_t*>(w + 3); r.episode = w + 4; r.tick = w + 5;
+    auto slot_ref = [&](int slot) {                               // LDS-typed pointers: ds_* instead of flat_* accesses
+        PPO_LDS char* b = (PPO_LDS char*)(my_slots + (size_t)slot * slot_bytes);
+        EnvRefLds r;
+        r.sc = (PPO_LDS int8_t*)b; r.dg = r.sc + a.envV;
+        PPO_LDS uint32_t* w = (PPO_LDS uint32_t*)(b + 2 * a.envV);
+        r.active = w; r.steps = (PPO_LDS int32_t*)(w + 1); r.reward = (PPO_LDS float*)(w + 2);
+        r.done = (PPO_LDS uint8_t*)(w + 3); r.episode = w + 4; r.tick = w + 5;
         return r;
     };
     if (MODE == 3) {
         ec.Q = a.envQ; ec.V = a.envV; ec.max_actions = a.env_max_actions; ec.no_action_reward = a.env_nar; ec.k0 = a.k0; ec.k1 = a.k1;
         int slot = 0;
         for (int64_t n = wave; n < a.B; n += nwaves, ++slot) {
-            const EnvRef r = slot_ref(slot);
+            const EnvRefLds r = slot_ref(slot);
             for (int v = lane; v < a.envV; v += 64) { r.sc[v] = a.env_score[n * a.envV + v]; r.dg[v] = a.env_degree[n * a.envV + v]; }
             if (lane == 0) {
                 *r.active = a.env_active[n]; *r.steps = a.env_steps[n]; *r.reward = a.env_reward[n];
-                *reinterpret_cast<uint32_t*>(r.done) = a.env_done[n]; *r.episode = a.env_episode[n]; *r.tick = a.env_tick[n];
+                *(PPO_LDS uint32_t*)r.done = a.env_done[n]; *r.episode = a.env_episode[n]; *r.tick = a.env_tick[n];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slots are wave-private: program order + in-order LDS suffice
+    }
+    uint32_t tmpl_regs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3, TPS == 1: this lane's 36 template vertex ids
+    if (MODE == 3 && TPS == 1) {
+        const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tmpl_regs[k] = tp[k];
     }
     const int64_t t_steps = (MODE == 3) ? a.T : 1;
     for (int64_t tt = 0; tt < t_steps; ++tt) {
     int slot = 0;
     for (int64_t state = wave; state < a.B; state += nwaves, ++slot) {
         const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
-        EnvRef er;
+        EnvRefLds er = {};
         if (MODE == 3) er = slot_ref(slot);
         const uint32_t act = (MODE == 3) ? *er.active : a.active[sid];
         const uint32_t tick_val = (MODE == 3) ? *er.tick : ((MODE == 1) ? a.tick[state] : 0u);
@@ -152,8 +158,16 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             if (MODE == 3) {
                 // state(env): this lane's 36 features of half-edge row 32*ts + j, recorded into the rollout buffer
                 static_assert(MODE != 3 || XW == 9, "the built-in env has F = 72 features");
-                uint32_t ob[9];
-                env_observe_lane(er, a.env_tmpl + (32 * ts + j) * PPO_TPL, 32 * ts + j, h, ob);
+                uint32_t ob[9], tid[9];
+                if (TPS == 1) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tid[k] = tmpl_regs[k];          // row j's ids, loaded once per kernel
+                } else {
+                    const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + (32 * ts + j) * PPO_TPL);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tid[k] = tp[k];
+                }
+                env_observe_lane(er, tid, 32 * ts + j, h, ob);
                 uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + ((size_t)out_index * TPS + ts) * 32 * F +
                                                            (size_t)j * F + (size_t)h * XB);
 #pragma unroll
@@ -290,7 +304,17 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             // update!: the observed mask, then step!(env, a), reward, is_terminal (src/collect_rollouts.jl:9-14) and the
             // reset! before the next episode (src/rollout_buffer.jl:75) -- one lane, on the LDS slot
             asm volatile("" ::: "memory");
-            if (lane == 0) {
+            if (TPS == 1) {                                  // Q == 8: wavefront-parallel env update (one state byte per lane)
+                float rew; uint8_t dn;
+                const int errf = env_step_wave32(ec, er, sampled, lane, rew, dn);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    a.active_out[out_index] = act;
+                    if (errf) atomicOr(a.err, errf);
+                    a.rew_out[out_index] = rew; a.done_out[out_index] = dn;
+                }
+                if (dn) env_reset_wave32(ec, er, (uint32_t)(a.global_offset + state), lane);
+            } else if (lane == 0) {
                 a.active_out[out_index] = act;
                 float rew; uint8_t dn;
                 const int errf = env_step_ref(ec, er, sampled, rew, dn);
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     if (MODE == 3) {                                            // env state back to the [N] arrays
         int slot2 = 0;
         for (int64_t n = wave; n < a.B; n += nwaves, ++slot2) {
-            const EnvRef r = slot_ref(slot2);
+            const EnvRefLds r = slot_ref(slot2);
             for (int v = lane; v < a.envV; v += 64) { a.env_score[n * a.envV + v] = r.sc[v]; a.env_degree[n * a.envV + v] = r.dg[v]; }
             if (lane == 0) {
                 a.env_active[n] = *r.active; a.env_steps[n] = *r.steps; a.env_reward[n] = *r.reward;

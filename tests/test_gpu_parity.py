@@ -225,7 +225,7 @@ def rollout_mode(request, P):
     """Both rollout executions: three launches per step, and the whole T-step rollout in one launch (MODE 3)."""
     P.set_rollout_persistent(request.param)
     yield request.param
-    P.set_rollout_persistent(False)
+    P.set_rollout_persistent(None)
 
 
 @pytest.mark.parametrize("case", range(10))
