@@ -166,6 +166,7 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
 // bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
 struct FwdArgs;
 int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t B, int tps);
+int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& args, int64_t N, int tps, int V);
 int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 static inline int bf16_ks1(int F) { return (F + 15) / 16; }     // layer-1 k-steps of 16 (zero padded)
 int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);

@@ -23,6 +23,7 @@
 // contract over the 32 rows (dW2, dW3; dZ1 and X are emitted as fragments for the dW1 kernel); dH1 = W2^T dZ2
 // takes dZ2 lane-linear in accumulator-fragment order.
 #include "ppo_policy_tail.h"
+#include "ppo_env_device.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
     uint4* const sW3 = sW2 + C::W2_U4;
     float4* const sB1 = reinterpret_cast<float4*>(sW3 + C::W3_U4);
     float4* const sB2 = sB1 + NT * 8;
+    char* const env_lds = reinterpret_cast<char*>(sB2 + NT * 8);     // MODE 3: env slots of the 8 waves
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < C::W2_U4; i += 512) sW2[i] = a.w2b[i];
@@ -79,9 +81,50 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
     // layer-3 A operand: rows 0..3 of the 32-row operand tile are W3, the rest zero (lanes j >= 4 read the zero block)
     const int w3_lane = (j < 4) ? (h * 4 + j) : -1;
 
-    for (int64_t state = (int64_t)blockIdx.x * 8 + w; state < a.B; state += (int64_t)gridDim.x * 8) {
+    // ---- MODE 3: persistent rollout (see k_policy_fwd): every wave walks its envs through all T steps; W2 is staged in
+    // LDS once per ROLLOUT instead of once per step.  Env state lives in the wave's LDS slots.
+    const int64_t wave0 = (int64_t)blockIdx.x * 8 + w, nwaves = (int64_t)gridDim.x * 8;
+    const int slot_bytes = 2 * a.envV + 32;
+    char* const my_slots = env_lds + (size_t)w * a.env_slots * slot_bytes;
+    EnvConst ec = {};
+    auto slot_ref = [&](int slot) {
+        PPO_LDS char* b = (PPO_LDS char*)(my_slots + (size_t)slot * slot_bytes);
+        EnvRefLds r;
+        r.sc = (PPO_LDS int8_t*)b; r.dg = r.sc + a.envV;
+        PPO_LDS uint32_t* ww = (PPO_LDS uint32_t*)(b + 2 * a.envV);
+        r.active = ww; r.steps = (PPO_LDS int32_t*)(ww + 1); r.reward = (PPO_LDS float*)(ww + 2);
+        r.done = (PPO_LDS uint8_t*)(ww + 3); r.episode = ww + 4; r.tick = ww + 5;
+        return r;
+    };
+    uint32_t tmpl_regs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (MODE == 3) {
+        ec.Q = a.envQ; ec.V = a.envV; ec.max_actions = a.env_max_actions; ec.no_action_reward = a.env_nar; ec.k0 = a.k0; ec.k1 = a.k1;
+        int slot = 0;
+        for (int64_t n = wave0; n < a.B; n += nwaves, ++slot) {
+            const EnvRefLds r = slot_ref(slot);
+            for (int v = lane; v < a.envV; v += 64) { r.sc[v] = a.env_score[n * a.envV + v]; r.dg[v] = a.env_degree[n * a.envV + v]; }
+            if (lane == 0) {
+                *r.active = a.env_active[n]; *r.steps = a.env_steps[n]; *r.reward = a.env_reward[n];
+                *(PPO_LDS uint32_t*)r.done = a.env_done[n]; *r.episode = a.env_episode[n]; *r.tick = a.env_tick[n];
+            }
+        }
+        if (TPS == 1) {
+            const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) tmpl_regs[k] = tp[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const int64_t t_steps = (MODE == 3) ? a.T : 1;
+    for (int64_t tstep = 0; tstep < t_steps; ++tstep) {
+    int slot = 0;
+    for (int64_t state = wave0; state < a.B; state += nwaves, ++slot) {
         const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
-        const uint32_t act = a.active[sid];
+        EnvRefLds er = {};
+        if (MODE == 3) er = slot_ref(slot);
+        const uint32_t act = (MODE == 3) ? *er.active : a.active[sid];
+        const uint32_t tick_val = (MODE == 3) ? *er.tick : ((MODE == 1) ? a.tick[state] : 0u);
+        const int64_t out_index = (MODE == 3) ? tstep * a.B + state : state;
         float l[TPS][4];
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) l[tt][0] = l[tt][1] = l[tt][2] = l[tt][3] = 0.0f;
@@ -90,12 +133,44 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
             const int64_t tile = state * TPS + ts;
             // ---- state rows -> layer-1 B operands: lane (row j, half h) holds features 16s + 8h .. +7 of k-step s
             const int8_t* row = a.states + ((size_t)sid * TPS + ts) * 32 * F + (size_t)j * F;
+            uint32_t ob[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3: this lane's 36 observed features (half h of row j)
+            if (MODE == 3) {
+                static_assert(MODE != 3 || F == 72, "the built-in env has F = 72 features");
+                uint32_t tid9[9];
+                if (TPS == 1) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tid9[k] = tmpl_regs[k];
+                } else {
+                    const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + (32 * ts + j) * PPO_TPL);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tid9[k] = tp[k];
+                }
+                env_observe_lane(er, tid9, 32 * ts + j, h, ob);
+                uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + ((size_t)out_index * TPS + ts) * 32 * F + (size_t)j * F + (size_t)h * 36);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) so[k] = ob[k];
+            }
             uint4 xs[KS1];
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
                 const int off = 16 * s + 8 * h;
                 uint2 d = make_uint2(0u, 0u);
-                if (off < F) d = *reinterpret_cast<const uint2*>(row + off);
+                if (MODE == 3) {
+                    // layer-1 k-step s wants features [16s + 8h, +8) of row j; the row's features sit 36 per lane half
+                    // (lane j: 0..35, lane j + 32: 36..71) as 9 dwords each: pull the two dwords from the lane half that
+                    // observed them.  Source half and dword index are compile-time per (s, destination half).
+                    uint32_t lo[2] = {0u, 0u}, hi[2] = {0u, 0u};
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int o0 = 16 * s + 8 * hh, o4 = o0 + 4;
+                        if (o0 < F) {
+                            const int lh = o0 >= 36 ? 1 : 0, hh4 = o4 >= 36 ? 1 : 0;
+                            lo[hh] = __shfl(ob[(o0 - 36 * lh) >> 2], j + 32 * lh);
+                            hi[hh] = __shfl(ob[(o4 - 36 * hh4) >> 2], j + 32 * hh4);
+                        }
+                    }
+                    d = make_uint2(h ? lo[1] : lo[0], h ? hi[1] : hi[0]);
+                } else if (off < F) d = *reinterpret_cast<const uint2*>(row + off);
                 float f[8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -179,7 +254,41 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l[tt][i] = (tt == ts) ? lg[i] : l[tt][i];
         }
-        policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, (MODE == 1) ? a.tick[state] : 0u, state);
+        const int sampled = policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, tick_val, out_index);
+        if (MODE == 3) {
+            asm volatile("" ::: "memory");
+            if (TPS == 1) {                                  // Q == 8: wavefront-parallel env update
+                float rew; uint8_t dn;
+                const int errf = env_step_wave32(ec, er, sampled, lane, rew, dn);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    a.active_out[out_index] = act;
+                    if (errf) atomicOr(a.err, errf);
+                    a.rew_out[out_index] = rew; a.done_out[out_index] = dn;
+                }
+                if (dn) env_reset_wave32(ec, er, (uint32_t)(a.global_offset + state), lane);
+            } else if (lane == 0) {
+                a.active_out[out_index] = act;
+                float rew; uint8_t dn;
+                const int errf = env_step_ref(ec, er, sampled, rew, dn);
+                if (errf) atomicOr(a.err, errf);
+                a.rew_out[out_index] = rew; a.done_out[out_index] = dn;
+                if (dn) env_reset_ref(ec, er, (uint32_t)(a.global_offset + state));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    }
+    if (MODE == 3) {                                            // env state back to the [N] arrays
+        int slot2 = 0;
+        for (int64_t n = wave0; n < a.B; n += nwaves, ++slot2) {
+            const EnvRefLds r = slot_ref(slot2);
+            for (int v = lane; v < a.envV; v += 64) { a.env_score[n * a.envV + v] = r.sc[v]; a.env_degree[n * a.envV + v] = r.dg[v]; }
+            if (lane == 0) {
+                a.env_active[n] = *r.active; a.env_steps[n] = *r.steps; a.env_reward[n] = *r.reward;
+                a.env_done[n] = *r.done; a.env_episode[n] = *r.episode; a.env_tick[n] = *r.tick;
+            }
+        }
     }
 }
 
@@ -204,6 +313,34 @@ static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B
     else if (p->F == 72 && p->HID == 128 && tps == 4) LAUNCHB(72, 128, 4);
     else { ppo_set_error("unsupported policy/state shape (F,HID,H) for the gfx950 bf16 kernels"); return PPO_ERR_UNSUPPORTED; }
 #undef LAUNCHB
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+// persistent rollout in bf16 mode: `a` comes filled from launch_policy_rollout_persistent (ppo_policy_fwd.hip)
+int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V) {
+    const int64_t need = (N + 7) / 8;
+    const unsigned grid = (unsigned)(need < 256 ? need : 256);
+    const int slots = (int)((N + (int64_t)grid * 8 - 1) / ((int64_t)grid * 8));
+    a.env_slots = slots;
+    a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
+    const size_t env_bytes = (size_t)8 * slots * (2 * V + 32);
+#define LAUNCHP(HH, TT)                                                                                              \
+    do {                                                                                                             \
+        const size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                      \
+        if (lds > 160 * 1024) return PPO_ERR_UNSUPPORTED;                                                            \
+        static size_t attr_lds = 0;                                                                                  \
+        if (lds > attr_lds) {                                                                                        \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<72, HH, 3, TT>,                               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            attr_lds = lds;                                                                                          \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_policy_fwd_bf16<72, HH, 3, TT>), dim3(grid), dim3(512), lds, ppo_stream(), a);         \
+    } while (0)
+    if (p->HID == 256 && tps == 1) LAUNCHP(256, 1);
+    else if (p->HID == 128 && tps == 1) LAUNCHP(128, 1);
+    else return PPO_ERR_UNSUPPORTED;
+#undef LAUNCHP
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }

@@ -427,7 +427,7 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 // Persistent rollout (MODE 3): T steps of all N envs in one launch.  Returns PPO_ERR_UNSUPPORTED (without setting an
 // error) when the shape is not covered, so the caller falls back to the per-step launches.
 int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs) {
-    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || e->F != 72) return PPO_ERR_UNSUPPORTED;
+    if (p->F != 72 || e->F != 72) return PPO_ERR_UNSUPPORTED;
     const int tps = e->H / 32;
     const int64_t N = e->N;
     const int64_t need = (N + 3) / 4;
@@ -436,7 +436,7 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     const unsigned grid = (unsigned)(need < cap ? need : cap);
     const int slots = (int)((N + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4));
     const size_t lds = (size_t)4 * slots * (2 * e->V + 32);
-    if (lds > 96 * 1024) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype == PPO_DTYPE_F32 && lds > 96 * 1024) return PPO_ERR_UNSUPPORTED;
     FwdArgs a = {};
     fill_weights(p, a);
     a.B = N; a.T = T;
@@ -449,6 +449,7 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     a.rew_out = ro->rewards.p; a.done_out = ro->done.p;
     a.full_probs = record_probs ? ro->full_probs.p : nullptr;
     ProfScope ps("k_rollout_persistent");
+    if (p->dtype == PPO_DTYPE_BF16) return launch_policy_rollout_persistent_bf16(p, a, N, tps, e->V);
 #define LAUNCH3(HH, TT)                                                                                      \
     do {                                                                                                     \
         static size_t attr_lds = 0;                                                                          \
