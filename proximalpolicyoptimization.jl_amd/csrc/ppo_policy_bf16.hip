@@ -25,6 +25,10 @@
 #include "ppo_policy_tail.h"
 #include "ppo_env_device.h"
 
+#ifndef PPO_BF16_ACT_NT
+#define PPO_BF16_ACT_NT 1
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -49,6 +53,17 @@ __device__ __forceinline__ void pack_tile(const f32x16& acc, uint4 (&out)[2]) {
 // leakyrelu'(h) for the two bf16 values of a packed dword: h > 0 <=> the bit pattern read as int16 is > 0
 __device__ __forceinline__ float slope_lo(uint32_t d) { return (int16_t)(d & 0xFFFFu) > 0 ? 1.0f : 0.01f; }
 __device__ __forceinline__ float slope_hi(uint32_t d) { return (int32_t)d >= 0x10000 ? 1.0f : 0.01f; }
+// saved activations are written once and read once by the backward pass much later: non-temporal stores keep them from
+// churning the L2 (same as the fp32 forward kernel)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void act_store_nt_u4(uint4* p, const uint4& v) {
+#if PPO_BF16_ACT_NT
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // ================================================================ forward
@@ -207,8 +222,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
                     pack_tile(acc, h1p[o]);
                     if (MODE == 2) {
-                        a.act1b[((size_t)tile * NT + o) * 128 + lane] = h1p[o][0];
-                        a.act1b[((size_t)tile * NT + o) * 128 + 64 + lane] = h1p[o][1];
+                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
+                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -236,8 +251,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 uint4 h2p[2];
                 pack_tile(acc, h2p);
                 if (MODE == 2) {
-                    a.act2b[((size_t)tile * NT + o) * 128 + lane] = h2p[0];
-                    a.act2b[((size_t)tile * NT + o) * 128 + 64 + lane] = h2p[1];
+                    act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + lane, h2p[0]);
+                    act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + 64 + lane, h2p[1]);
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
