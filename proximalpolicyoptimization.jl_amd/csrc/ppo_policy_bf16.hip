@@ -28,6 +28,9 @@
 #ifndef PPO_BF16_ACT_NT
 #define PPO_BF16_ACT_NT 1
 #endif
+#ifndef PPO_BF16_ACT_NT_LOAD
+#define PPO_BF16_ACT_NT_LOAD 1
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -413,6 +416,17 @@ struct BwdB {
 __device__ __forceinline__ uint4 ldg16(const void* sbase, unsigned voff) {
     return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sbase) + voff);
 }
+// read-once streams (the saved activations in the backward pass): non-temporal, so they do not evict the W2^T
+// fragments and the dW1 operand fragments that ARE re-read
+__device__ __forceinline__ uint4 ldg16_nt(const void* sbase, unsigned voff) {
+#if PPO_BF16_ACT_NT_LOAD
+    typedef uint32_t u32x4l __attribute__((ext_vector_type(4)));
+    const u32x4l t = __builtin_nontemporal_load(reinterpret_cast<const u32x4l*>(reinterpret_cast<const char*>(sbase) + voff));
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return ldg16(sbase, voff);
+#endif
+}
 __device__ __forceinline__ void stg16(void* sbase, unsigned voff, const uint4& v) {
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(sbase) + voff) = v;
 }
@@ -513,8 +527,8 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
         for (int i = 0; i < FT; ++i) {
             const size_t base = ((size_t)t * NT + (w * FT + i)) * 128;          // wave-uniform
-            nh2[i][0] = ldg16(a.act2b + base, lo16); nh2[i][1] = ldg16(a.act2b + base + 64, lo16);
-            nh1[i][0] = ldg16(a.act1b + base, lo16); nh1[i][1] = ldg16(a.act1b + base + 64, lo16);
+            nh2[i][0] = ldg16_nt(a.act2b + base, lo16); nh2[i][1] = ldg16_nt(a.act2b + base + 64, lo16);
+            nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16);
         }
         ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
         const char* xs = reinterpret_cast<const char*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
