@@ -25,6 +25,14 @@
 #ifndef PPO_BWD_LD
 #define PPO_BWD_LD 36
 #endif
+#ifndef PPO_BWD_ACT_NT
+#define PPO_BWD_ACT_NT 1          // read-once saved activations: non-temporal loads
+#endif
+#if PPO_BWD_ACT_NT
+#define PPO_BWD_NT_SFX " nt"
+#else
+#define PPO_BWD_NT_SFX ""
+#endif
 #ifndef PPO_BWD_KG
 #define PPO_BWD_KG 2
 #endif
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
             unsigned keep;
             const float4* gsrc = src + q * 64;
             const unsigned dst = h2slice_lds + (unsigned)q * 1024u;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" PPO_BWD_NT_SFX "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
         }
     };
@@ -132,7 +140,15 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         // scalar (SGPR) base + 32-bit per-lane byte offset -> saddr-form loads, no per-lane 64-bit pointers
         const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)t * NT + w) * 4 * 64);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v1[q] = *reinterpret_cast<const float4*>(s1 + (lo16 + (unsigned)q * 1024u));
+        for (int q = 0; q < 4; ++q) {
+#if PPO_BWD_ACT_NT
+            typedef float f32x4l __attribute__((ext_vector_type(4)));
+            const f32x4l t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4l*>(s1 + (lo16 + (unsigned)q * 1024u)));
+            v1[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
+#else
+            v1[q] = *reinterpret_cast<const float4*>(s1 + (lo16 + (unsigned)q * 1024u));
+#endif
+        }
         dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
         const char* xs = reinterpret_cast<const char*>(a.states + ((size_t)sidx * a.tps + (size_t)(t % a.tps)) * 32 * F);
 #pragma unroll
