@@ -28,6 +28,18 @@
 #ifndef PPO_BF16_ACT_NT
 #define PPO_BF16_ACT_NT 1
 #endif
+#ifndef PPO_BF16_BWD_DL
+#define PPO_BF16_BWD_DL 3
+#endif
+#ifndef PPO_BF16_RING_SPREAD
+#define PPO_BF16_RING_SPREAD 1
+#endif
+#ifndef PPO_BF16_EMIT_SPREAD
+#define PPO_BF16_EMIT_SPREAD 0          // measured: no gain (the store stall just moves under dW2)
+#endif
+#ifndef PPO_BF16_PF_POS
+#define PPO_BF16_PF_POS 2
+#endif
 #ifndef PPO_BF16_ACT_NT_LOAD
 #define PPO_BF16_ACT_NT_LOAD 1
 #endif
@@ -538,6 +550,25 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             nx[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
         }
     };
+    // the same loads one at a time (piece k of 4 FT + 2), to be spread between the MFMAs of phase B: issued in one
+    // burst they stall the wave for ~1200 cycles (the CU's miss queue back-pressures the issue), and nothing overlaps
+    auto prefetch_piece = [&](int k, int t, int sidx) {
+        if (k < 4 * FT) {
+            const int i = k >> 2;
+            const size_t base = ((size_t)t * NT + (w * FT + i)) * 128 + ((k & 1) ? 64 : 0);
+            if (k & 2) nh1[i][k & 1] = ldg16_nt(a.act1b + base, lo16);
+            else       nh2[i][k & 1] = ldg16_nt(a.act2b + base, lo16);
+        } else if (k == 4 * FT) {
+            ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+        } else if (k == 4 * FT + 1) {
+            const char* xs = reinterpret_cast<const char*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
+#pragma unroll
+            for (int i = 0; i < XPD; ++i) {
+                const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
+                nx[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+            }
+        }
+    };
     auto tile_or_last = [&](int t) { return t < a.B ? t : a.B - 1; };
     int idx_next = 0;
     if ((int)blockIdx.x < a.B) {
@@ -572,10 +603,13 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         // for the prefetched inputs, so they land under phase A (sched_barrier: hipcc otherwise sinks them to the barrier)
         uint4 ring[NSH][FT];
         const uint4* wt = a.w2tb + (size_t)(w * FT) * NS * 64;       // wave-uniform base of this wave's W2^T tiles
+        // (k-step order = the order the chain consumes them in: vmcnt retires in order).  PPO_BF16_RING_SPREAD: not in
+        // one burst -- 16 KiB per wave through a 64 B/clk L1 stalls the issuing wave ~1000 cycles -- but a few at a
+        // time between the pieces of phase A's VALU/LDS work
+        auto ring_load = [&](int q) { ring[q / FT][q % FT] = ldg16(wt + (size_t)((q % FT) * NS + NSH + q / FT) * 64, lo16); };
+        constexpr bool SPREAD = PPO_BF16_RING_SPREAD && (NSH * FT == 4 + FT * 6);      // schedule written for HID = 256
 #pragma unroll
-        for (int g = 0; g < NSH; ++g)
-#pragma unroll
-            for (int i = 0; i < FT; ++i) ring[g][i] = ldg16(wt + (size_t)(i * NS + NSH + g) * 64, lo16);
+        for (int q = 0; q < (SPREAD ? 4 : NSH * FT); ++q) ring_load(q);
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
@@ -593,6 +627,11 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 const uint32_t d = dw(nh2[i][r >> 3], (r >> 1) & 3);
                 acc[r] = acc[r] * ((r & 1) ? slope_hi(d) : slope_lo(d));
             }
+            if constexpr (SPREAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                ring_load(4 + 6 * i); ring_load(5 + 6 * i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             uint4 zf[2];
             pack_tile(acc, zf);
             sZF[(2 * ft) * 64 + lane] = zf[0];
@@ -603,6 +642,11 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 *reinterpret_cast<uint2*>(imgZ2 + off) = make_uint2(dw(zf[g >> 1], 2 * (g & 1)), dw(zf[g >> 1], 2 * (g & 1) + 1));
                 *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
                 *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[i][g >> 1], 2 * (g & 1)), dw(nh1[i][g >> 1], 2 * (g & 1) + 1));
+                if constexpr (SPREAD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring_load(6 + 6 * i + g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         BSTAMP(1);
@@ -613,8 +657,16 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A).  They
             // are issued BEHIND the streamed W2^T half: vmcnt retires in order, so the chain below waits only for
             // fragments that are older than these loads
+#if PPO_BF16_PF_POS == 0
             prefetch(tile_or_last(tile + a.nwg), idx_next);   // harmless re-load behind the last tile
             idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
+#endif
+#if PPO_BF16_PF_POS == 2
+            static_assert(4 * FT + 2 <= NS, "one prefetch piece per k-step");
+            constexpr int PF_T0 = 0;
+            const int pf_tile = tile_or_last(tile + a.nwg), pf_sidx = __builtin_amdgcn_readfirstlane(idx_next);
+            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
+#endif
             f32x16 acc[FT];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -623,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // The k-steps whose W2^T fragments were streamed into registers run first (their registers free up), then
             // the LDS-resident ones.  LDS operands are read DL steps ahead of their MFMAs (explicit queue; sched_barrier
             // pins the order): one step ahead covers 64 cycles of MFMA, a ds_read_b128 round trip is longer than that.
-            constexpr int DL = 3;
+            constexpr int DL = PPO_BF16_BWD_DL;
             uint4 bzq[DL], wlq[DL][FT];
             auto kstep = [&](int t) { return t < NSH ? t + NSH : t - NSH; };
             auto issue = [&](int t) {
@@ -648,7 +700,18 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
                 for (int i = 0; i < FT; ++i) acc[i] = mfma_bf16(wv[i], bz, acc[i]);
                 __builtin_amdgcn_sched_barrier(0);
+#if PPO_BF16_PF_POS == 2
+                if (t >= PF_T0 && t - PF_T0 < 4 * FT + 2) prefetch_piece(t - PF_T0, pf_tile, pf_sidx);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef PPO_BF16_STAMP_MID
+                if (t == NSH - 1) BSTAMP(6);
+#endif
             }
+#if PPO_BF16_PF_POS == 1
+            prefetch(tile_or_last(tile + a.nwg), idx_next);
+            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
+#endif
             BSTAMP(3);
 #pragma unroll
             for (int i = 0; i < FT; ++i) {
@@ -680,6 +743,21 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // (interleaving these MFMAs with the dH1 chain to hide its W2^T refills was measured slower: the chain's
             // two working accumulators then compete with the 256 resident ones for the AGPR half and hipcc parks two
             // dW2 tiles in scratch)
+            auto emit_z = [&](int i, int s) {
+                const uint4 z = tr_frag(imgZ1 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ1 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+                db1[i] += sum_frag(z);
+                stg16(a.z1f + (((size_t)tile * NT + (w * FT + i)) * 2 + s) * 64, lo16, z);
+            };
+            auto emit_x = [&](int i) {
+                const int it = w * FT + i;                     // wave-uniform
+                if (it < NI) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        stg16(a.xf + (((size_t)tile * NI + it) * 2 + s) * 64, lo16,
+                              tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it));
+                }
+            };
+            static_assert(!PPO_BF16_EMIT_SPREAD || 3 * FT <= NT, "one emit per column tile");
             uint4 az[FT][2];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -697,6 +775,11 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 for (int i = 0; i < FT; ++i)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
+#if PPO_BF16_EMIT_SPREAD
+                // the operand fragments for k_policy_dw1_bf16 leave one store per column tile, under this tile's MFMAs
+                if (kt < 2 * FT) emit_z(kt >> 1, kt & 1);
+                else if (kt < 3 * FT) emit_x(kt - 2 * FT);
+#endif
             }
             BSTAMP(5);
             // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
@@ -715,27 +798,19 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                         dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
                     }
                 }
+#ifndef PPO_BF16_STAMP_MID
             BSTAMP(6);
+#endif
             // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
             // for k_policy_dw1_bf16
+#if !PPO_BF16_EMIT_SPREAD
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 z = tr_frag(imgZ1 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ1 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
-                    db1[i] += sum_frag(z);
-                    stg16(a.z1f + (((size_t)tile * NT + (w * FT + i)) * 2 + s) * 64, lo16, z);
-                }
+                for (int s = 0; s < 2; ++s) emit_z(i, s);
 #pragma unroll
-            for (int i = 0; i < FT; ++i) {
-                const int it = w * FT + i;                     // wave-uniform
-                if (it < NI) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        stg16(a.xf + (((size_t)tile * NI + it) * 2 + s) * 64, lo16,
-                              tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it));
-                }
-            }
+            for (int i = 0; i < FT; ++i) emit_x(i);
+#endif
         }
         __syncthreads();
         BSTAMP(7);
