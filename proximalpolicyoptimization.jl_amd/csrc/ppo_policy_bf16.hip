@@ -37,6 +37,15 @@
 #ifndef PPO_BF16_EMIT_SPREAD
 #define PPO_BF16_EMIT_SPREAD 0          // measured: no gain (the store stall just moves under dW2)
 #endif
+#ifndef PPO_BF16_STAGE_ROTATE
+#define PPO_BF16_STAGE_ROTATE 1
+#endif
+#ifndef PPO_BF16_PF1
+#define PPO_BF16_PF1 6
+#endif
+#ifndef PPO_BF16_STORE_LATE
+#define PPO_BF16_STORE_LATE 1
+#endif
 #ifndef PPO_BF16_PF_POS
 #define PPO_BF16_PF_POS 2
 #endif
@@ -103,7 +112,28 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
     char* const env_lds = reinterpret_cast<char*>(sB2 + NT * 8);     // MODE 3: env slots of the 8 waves
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < C::W2_U4; i += 512) sW2[i] = a.w2b[i];
+#ifdef PPO_BF16_STAMP
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0}, st_t = clock64();
+#define FBSTAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define FBSTAMP(i) do {} while (0)
+#endif
+    // every workgroup stages the same 2*HID^2 bytes: start each one at a different 8 KiB chunk so the CUs of an XCD do
+    // not all pull the same L2 lines (same channel) at the same moment
+    {
+        constexpr int NCH = C::W2_U4 / 512;
+        static_assert(C::W2_U4 % 512 == 0, "W2 staging chunks");
+#if PPO_BF16_STAGE_ROTATE
+        const int rot = (int)(blockIdx.x >> 3);
+#else
+        const int rot = 0;
+#endif
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int i = ((k + rot) % NCH) * 512 + tid;
+            sW2[i] = a.w2b[i];
+        }
+    }
     for (int i = tid; i < NS * 8; i += 512) sW3[i] = a.w3c[i];
     if (tid == 0) sW3[NS * 8] = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < NT * 8; i += 512) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
@@ -146,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     const int64_t t_steps = (MODE == 3) ? a.T : 1;
+    FBSTAMP(0);
     for (int64_t tstep = 0; tstep < t_steps; ++tstep) {
     int slot = 0;
     for (int64_t state = wave0; state < a.B; state += nwaves, ++slot) {
@@ -158,6 +189,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
         float l[TPS][4];
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) l[tt][0] = l[tt][1] = l[tt][2] = l[tt][3] = 0.0f;
+        TailPre tpre = {0, 0.0f, 0.0f};
+        if (MODE == 2 && PPO_BF16_STORE_LATE) { tpre.ab = a.actions[sid]; tpre.po = a.p_old[sid]; tpre.adv = a.adv[sid]; }
 #pragma unroll 1
         for (int ts = 0; ts < TPS; ++ts) {
             const int64_t tile = state * TPS + ts;
@@ -209,11 +242,12 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 }
                 xs[s] = make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
             }
+            FBSTAMP(1);
             // ---- layer 1 (W1 fragments through L1: 1 KiB per wave load, PF1 of them in flight in a register ring;
             // sched_barrier keeps hipcc from hoisting the whole 40-fragment stream into registers)
             uint4 h1p[NT][2];
             {
-                constexpr int NG = NT * KS1, PF1 = (NG < 6) ? NG : 6;
+                constexpr int NG = NT * KS1, PF1 = (NG < PPO_BF16_PF1) ? NG : PPO_BF16_PF1;
                 const uint4* wp = a.w1b + lane;
                 uint4 ring[PF1];
 #pragma unroll
@@ -236,13 +270,24 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
                     pack_tile(acc, h1p[o]);
-                    if (MODE == 2) {
+                    if (MODE == 2 && !PPO_BF16_STORE_LATE) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // saved layer-1 activations leave AFTER the last W1 fragment has been waited for: loads and stores share
+                // the in-order vmcnt queue, so a store between two ring loads puts its HBM round trip on the MFMA chain
+                // (layer 2 takes its operands from LDS and never waits on vmcnt)
+                if (MODE == 2 && PPO_BF16_STORE_LATE) {
+#pragma unroll
+                    for (int o = 0; o < NT; ++o) {
+                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
+                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
+                    }
+                }
             }
+            FBSTAMP(2);
             // ---- layer 2 (W2 fragments from LDS) + layer 3 (two MFMAs per feature tile)
             f32x16 acc3;
 #pragma unroll
@@ -275,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                     acc3 = mfma_bf16(sW3[idx], h2p[s], acc3);
                 }
             }
+            FBSTAMP(3);
             // logits of row j sit in accumulator registers 0..3 of lane j (lane half 0): hand them to both halves
             float lg[4];
 #pragma unroll
@@ -284,7 +330,9 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l[tt][i] = (tt == ts) ? lg[i] : l[tt][i];
         }
-        const int sampled = policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, tick_val, out_index);
+        const int sampled = policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, tick_val, out_index,
+                                                         (MODE == 2 && PPO_BF16_STORE_LATE) ? &tpre : nullptr);
+        FBSTAMP(4);
         if (MODE == 3) {
             asm volatile("" ::: "memory");
             if (TPS == 1) {                                  // Q == 8: wavefront-parallel env update
@@ -307,8 +355,13 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+        FBSTAMP(5);
     }
     }
+#ifdef PPO_BF16_STAMP
+    if (a.stamps && lane == 0 && wave0 < 2048)
+        for (int i = 0; i < 6; ++i) a.stamps[wave0 * 6 + i] = st_sum[i];
+#endif
     if (MODE == 3) {                                            // env state back to the [N] arrays
         int slot2 = 0;
         for (int64_t n = wave0; n < a.B; n += nwaves, ++slot2) {
@@ -322,8 +375,24 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
     }
 }
 
+#ifdef PPO_BF16_STAMP
+static unsigned long long* g_bf16_fstamps = nullptr;
+extern "C" int32_t ppo_debug_bf16_fwd_stamps(unsigned long long* out) {
+    if (!g_bf16_fstamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_bf16_fstamps, 2048 * 6 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+static void set_fwd_stamps(FwdArgs& a) {
+    if (!g_bf16_fstamps) (void)hipMalloc((void**)&g_bf16_fstamps, 2048 * 6 * 8);
+    a.stamps = g_bf16_fstamps;
+}
+#else
+static void set_fwd_stamps(FwdArgs&) {}
+#endif
+
 template <int MODE>
 static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B, int tps) {
+    set_fwd_stamps(const_cast<FwdArgs&>(args));
     const int64_t need = (B + 7) / 8;
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
 #define LAUNCHB(FF, HH, TT)                                                                                          \
@@ -353,6 +422,7 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
     const int slots = (int)((N + (int64_t)grid * 8 - 1) / ((int64_t)grid * 8));
     a.env_slots = slots;
+    set_fwd_stamps(a);
     a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
     const size_t env_bytes = (size_t)8 * slots * (2 * V + 32);
 #define LAUNCHP(HH, TT)                                                                                              \

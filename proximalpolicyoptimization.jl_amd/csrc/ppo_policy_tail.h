@@ -56,13 +56,18 @@ __device__ __forceinline__ float dy_round(float x) {
     return (float)(__bf16)x;
 }
 
+// MODE 2 inputs of one transition, when the caller fetched them ahead of its own stores (vmcnt counts loads and stores
+// in one in-order queue on gfx9: a load issued behind a store cannot be waited for without waiting for the store)
+struct TailPre { int ab; float po; float adv; };
+
 // l[ts][i]: logit of action 128*ts + 4*j + i of the state, present in both lane halves (j = lane & 31).
 // MODE 1 / 3 (rollout): tick_val = the env's tick (Philox counter word), out_index = position of the transition in
 // the output columns (state for one step, t*N + state for the persistent rollout); returns the sampled action.
 template <int MODE, int TPS, bool DYBF16>
 __device__ __forceinline__ int policy_tail(const FwdArgs& a, const int64_t state, const int64_t sid, const uint32_t act,
                                            float (&l)[TPS][4], const int lane, const int j, const int h,
-                                           const uint32_t tick_val = 0u, const int64_t out_index = 0) {
+                                           const uint32_t tick_val = 0u, const int64_t out_index = 0,
+                                           const TailPre* pre = nullptr) {
     int sampled = 0;
     constexpr int A = 128 * TPS;
     // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
@@ -155,9 +160,9 @@ __device__ __forceinline__ int policy_tail(const FwdArgs& a, const int64_t state
         }
     }
     if (MODE == 2) {
-        const int ab = a.actions[sid];
-        const float po = a.p_old[sid];
-        const float adv = a.adv[sid];
+        const int ab = pre ? pre->ab : a.actions[sid];
+        const float po = pre ? pre->po : a.p_old[sid];
+        const float adv = pre ? pre->adv : a.adv[sid];
         float cand = 0.0f;
 #pragma unroll
         for (int ts = 0; ts < TPS; ++ts)
