@@ -6,6 +6,10 @@
 #include "ppo_internal.h"
 #include "ppo_device.h"
 
+#ifndef PPO_DPP_REDUCE
+#define PPO_DPP_REDUCE 1
+#endif
+
 struct FwdArgs {
     // inputs
     const int8_t* states;      // MODE 0/1: [B][H][F]; MODE 2: rollout states base (gathered by idx)
@@ -34,14 +38,33 @@ struct FwdArgs {
     const uint4* w1b; const uint4* w2b; const uint4* w3c; uint4* act1b; uint4* act2b;
 };
 
+// value of lane (lane ^ OFF), OFF < 32.  Same lane mapping as __shfl_xor (which hipcc lowers to ds_bpermute_b32: an
+// LDS round trip of ~100+ cycles per step, fully exposed in the one-or-two-waves-per-SIMD kernels here), but as DPP
+// moves where the xor is a DPP pattern (1, 2: quad_perm; 8: row_ror:8; 4: row_shl:4 / row_shr:4 on alternate banks)
+// and ds_swizzle (no address VGPR) for 16.  Bit-identical results: only the transport changes.
+template <int OFF>
+__device__ __forceinline__ float xor_lane(float v) {
+#if PPO_DPP_REDUCE
+    const int x = __float_as_int(v);
+    if (OFF == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));          // quad_perm:[1,0,3,2]
+    if (OFF == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));          // quad_perm:[2,3,0,1]
+    if (OFF == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                            // row_shl:4 -> banks 0, 2
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false));                   // row_shr:4 -> banks 1, 3
+    }
+    if (OFF == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));         // row_ror:8
+    if (OFF == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(x, 0x401F));                            // bitmode: xor 16
+#endif
+    return __shfl_xor(v, OFF);
+}
 __device__ __forceinline__ float wave32_max(float v) {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    v = fmaxf(v, xor_lane<16>(v)); v = fmaxf(v, xor_lane<8>(v)); v = fmaxf(v, xor_lane<4>(v));
+    v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<1>(v));
     return v;
 }
 __device__ __forceinline__ float wave32_sum(float v) {
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    v = v + xor_lane<16>(v); v = v + xor_lane<8>(v); v = v + xor_lane<4>(v);
+    v = v + xor_lane<2>(v); v = v + xor_lane<1>(v);
     return v;
 }
 __device__ __forceinline__ float readlane_f(float v, int l) {
