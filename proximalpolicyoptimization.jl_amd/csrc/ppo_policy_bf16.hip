@@ -28,26 +28,11 @@
 #ifndef PPO_BF16_ACT_NT
 #define PPO_BF16_ACT_NT 1
 #endif
-#ifndef PPO_BF16_BWD_DL
-#define PPO_BF16_BWD_DL 3
-#endif
 #ifndef PPO_BF16_RING_SPREAD
 #define PPO_BF16_RING_SPREAD 1
 #endif
-#ifndef PPO_BF16_EMIT_SPREAD
-#define PPO_BF16_EMIT_SPREAD 0          // measured: no gain (the store stall just moves under dW2)
-#endif
-#ifndef PPO_BF16_STAGE_ROTATE
-#define PPO_BF16_STAGE_ROTATE 1
-#endif
-#ifndef PPO_BF16_PF1
-#define PPO_BF16_PF1 6
-#endif
 #ifndef PPO_BF16_STORE_LATE
 #define PPO_BF16_STORE_LATE 1
-#endif
-#ifndef PPO_BF16_PF_POS
-#define PPO_BF16_PF_POS 2
 #endif
 #ifndef PPO_BF16_ACT_NT_LOAD
 #define PPO_BF16_ACT_NT_LOAD 1
@@ -118,21 +103,11 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #else
 #define FBSTAMP(i) do {} while (0)
 #endif
-    // every workgroup stages the same 2*HID^2 bytes: start each one at a different 8 KiB chunk so the CUs of an XCD do
-    // not all pull the same L2 lines (same channel) at the same moment
-    {
+    {   // unrolled: all the loads are in flight before the first LDS write waits for one (the rolled loop was 4 us slower)
         constexpr int NCH = C::W2_U4 / 512;
         static_assert(C::W2_U4 % 512 == 0, "W2 staging chunks");
-#if PPO_BF16_STAGE_ROTATE
-        const int rot = (int)(blockIdx.x >> 3);
-#else
-        const int rot = 0;
-#endif
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int i = ((k + rot) % NCH) * 512 + tid;
-            sW2[i] = a.w2b[i];
-        }
+        for (int k = 0; k < NCH; ++k) sW2[k * 512 + tid] = a.w2b[k * 512 + tid];
     }
     for (int i = tid; i < NS * 8; i += 512) sW3[i] = a.w3c[i];
     if (tid == 0) sW3[NS * 8] = make_uint4(0u, 0u, 0u, 0u);
@@ -247,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
             // sched_barrier keeps hipcc from hoisting the whole 40-fragment stream into registers)
             uint4 h1p[NT][2];
             {
-                constexpr int NG = NT * KS1, PF1 = (NG < PPO_BF16_PF1) ? NG : PPO_BF16_PF1;
+                constexpr int NG = NT * KS1, PF1 = (NG < 6) ? NG : 6;      // 12 measured slower
                 const uint4* wp = a.w1b + lane;
                 uint4 ring[PF1];
 #pragma unroll
@@ -727,16 +702,10 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A).  They
             // are issued BEHIND the streamed W2^T half: vmcnt retires in order, so the chain below waits only for
             // fragments that are older than these loads
-#if PPO_BF16_PF_POS == 0
-            prefetch(tile_or_last(tile + a.nwg), idx_next);   // harmless re-load behind the last tile
-            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
-#endif
-#if PPO_BF16_PF_POS == 2
             static_assert(4 * FT + 2 <= NS, "one prefetch piece per k-step");
             constexpr int PF_T0 = 0;
             const int pf_tile = tile_or_last(tile + a.nwg), pf_sidx = __builtin_amdgcn_readfirstlane(idx_next);
             idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
-#endif
             f32x16 acc[FT];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -745,7 +714,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // The k-steps whose W2^T fragments were streamed into registers run first (their registers free up), then
             // the LDS-resident ones.  LDS operands are read DL steps ahead of their MFMAs (explicit queue; sched_barrier
             // pins the order): one step ahead covers 64 cycles of MFMA, a ds_read_b128 round trip is longer than that.
-            constexpr int DL = PPO_BF16_BWD_DL;
+            constexpr int DL = 3;
             uint4 bzq[DL], wlq[DL][FT];
             auto kstep = [&](int t) { return t < NSH ? t + NSH : t - NSH; };
             auto issue = [&](int t) {
@@ -770,18 +739,9 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
                 for (int i = 0; i < FT; ++i) acc[i] = mfma_bf16(wv[i], bz, acc[i]);
                 __builtin_amdgcn_sched_barrier(0);
-#if PPO_BF16_PF_POS == 2
-                if (t >= PF_T0 && t - PF_T0 < 4 * FT + 2) prefetch_piece(t - PF_T0, pf_tile, pf_sidx);
+                if (t >= PF_T0 && t - PF_T0 < 4 * FT + 2) prefetch_piece(t - PF_T0, pf_tile, pf_sidx);   // harmless re-load behind the last tile
                 __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef PPO_BF16_STAMP_MID
-                if (t == NSH - 1) BSTAMP(6);
-#endif
             }
-#if PPO_BF16_PF_POS == 1
-            prefetch(tile_or_last(tile + a.nwg), idx_next);
-            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
-#endif
             BSTAMP(3);
 #pragma unroll
             for (int i = 0; i < FT; ++i) {
@@ -827,7 +787,6 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                               tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it));
                 }
             };
-            static_assert(!PPO_BF16_EMIT_SPREAD || 3 * FT <= NT, "one emit per column tile");
             uint4 az[FT][2];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -845,11 +804,6 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 for (int i = 0; i < FT; ++i)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
-#if PPO_BF16_EMIT_SPREAD
-                // the operand fragments for k_policy_dw1_bf16 leave one store per column tile, under this tile's MFMAs
-                if (kt < 2 * FT) emit_z(kt >> 1, kt & 1);
-                else if (kt < 3 * FT) emit_x(kt - 2 * FT);
-#endif
             }
             BSTAMP(5);
             // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
@@ -868,19 +822,15 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                         dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
                     }
                 }
-#ifndef PPO_BF16_STAMP_MID
             BSTAMP(6);
-#endif
             // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
             // for k_policy_dw1_bf16
-#if !PPO_BF16_EMIT_SPREAD
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) emit_z(i, s);
 #pragma unroll
             for (int i = 0; i < FT; ++i) emit_x(i);
-#endif
         }
         __syncthreads();
         BSTAMP(7);
