@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int XB = F / 2;          // bytes of the state row held by one lane
     constexpr int XW = XB / 4;
 #ifndef PPO_FWD_PF
-#define PPO_FWD_PF 8
+#define PPO_FWD_PF 16
 #endif
 #ifndef PPO_FWD_WGSYNC
 #define PPO_FWD_WGSYNC 0
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #ifndef PPO_FWD_OUNROLL
 #define PPO_FWD_OUNROLL 1
 #endif
-    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PPO_FWD_PF : 4;   // weight-fragment groups kept in flight per wave
+    constexpr int PFW = (PPO_FWD_PF < HID / 8) ? PPO_FWD_PF : HID / 8;     // at most the groups of one output tile
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : 4;   // weight-fragment groups kept in flight per wave
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;           // half-edge row inside the tile
