@@ -71,6 +71,71 @@ def cpu_baseline():
                       "minibatch %d, 2x256 MLP, %.1f s on 1 core" % (n_env, T, EPOCHS, B, dt)}
 
 
+def cpu_baseline_blas():
+    """Second CPU figure, closer to what the Julia reference does on a host: the same path with the Dense products and
+    their gradients on the host BLAS / autograd (torch CPU, Float32, all threads) instead of the scalar C restatement --
+    serial per-env forward + sample + step! in the rollout (src/collect_rollouts.jl:1-24), batched minibatch step
+    (src/train.jl:54-84).  Env dynamics and sampling come from the oracle.  Context only: never the headline."""
+    import torch
+    from oracle import oracle as orc
+    from oracle import np_oracle as npo
+    n_env, T, B = 64, 64, 1024
+    params = orc.glorot_params(F, HID, 2, seed=0)
+    layers = [(torch.tensor(W, dtype=torch.float32, requires_grad=True), torch.tensor(b, dtype=torch.float32, requires_grad=True))
+              for (W, b) in npo.unpack_params(params, F, HID, 2)]
+    flat = [t for wb in layers for t in wb]
+    opt = torch.optim.Adam(flat, lr=LR)
+
+    def probs_of(x, mask):                                     # x [B,32,F] float32, mask [B,128] (0 / -inf)
+        a = x
+        for (W, b) in layers[:-1]:
+            a = torch.nn.functional.leaky_relu(a @ W.T + b, 0.01)
+        W, b = layers[-1]
+        return torch.softmax((a @ W.T + b).reshape(x.shape[0], -1) + mask, dim=1)
+
+    env = orc.Env(Q=8, max_actions=T_STEPS, N=n_env, seed=1234)
+    env.reset()
+    rng = np.random.default_rng(0)
+    M = n_env * T
+    st = np.zeros((M, 32, F), np.int8); msk = np.zeros((M, 128), np.float32)
+    a0 = np.zeros(M, np.int64); po = np.zeros(M, np.float32); rew = np.zeros((T, n_env), np.float32); dn = np.zeros((T, n_env), np.uint8)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in range(T):
+            obs = env.observe(); act = np.array(env.active)
+            acts = np.zeros(n_env, np.int32)
+            for n in range(n_env):                             # the reference walks one env at a time
+                mask = np.repeat(np.where((act[n] >> np.arange(8)) & 1, 0.0, -np.inf).astype(np.float32), 16)
+                p = probs_of(torch.from_numpy(obs[n:n + 1].astype(np.float32)), torch.from_numpy(mask[None]))[0].numpy()
+                a = min(int(np.searchsorted(np.cumsum(p), rng.random())), 127)
+                if not p[a] > 0:
+                    a = int(np.flatnonzero(p > 0)[-1])
+                k = t * n_env + n
+                st[k] = obs[n]; msk[k] = mask; a0[k] = a; po[k] = p[a]; acts[n] = a
+            env.step(acts)
+            rew[t] = env.reward; dn[t] = env.done
+            for n in np.flatnonzero(dn[t]):
+                env.reset_one(int(n))
+    ret = orc.compute_returns_tn(rew, dn, GAMMA).reshape(M)
+    X = torch.from_numpy(st.astype(np.float32)); Mk = torch.from_numpy(msk)
+    A0 = torch.from_numpy(a0); PO = torch.from_numpy(po); ADV = torch.from_numpy(ret.astype(np.float32))
+    for _ in range(EPOCHS):
+        perm = torch.from_numpy(rng.permutation(M))
+        for s0 in range(0, M, B):
+            sel = perm[s0:s0 + B]
+            p = probs_of(X[sel], Mk[sel])
+            adv = ADV[sel]
+            gain = p[torch.arange(len(sel)), A0[sel]] / PO[sel] * adv
+            clip = torch.where(adv >= 0, (1.0 + EPS) * adv, (1.0 - EPS) * adv)
+            sp = p + 1e-8 / 128
+            loss = -torch.mean(torch.minimum(gain, clip)) + ENT_W * torch.mean((sp * torch.log(sp)).sum(dim=1))
+            opt.zero_grad(); loss.backward(); opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": M / dt, "unit": "env-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "same path with the MLP on host BLAS/autograd (torch CPU fp32): %d envs x %d steps, %d epochs, "
+                      "minibatch %d, %.1f s on %d threads" % (n_env, T, EPOCHS, B, dt, torch.get_num_threads())}
+
+
 def main():
     global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS
     ap = argparse.ArgumentParser()
@@ -242,6 +307,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:      # the oracle is only a reported baseline
                 out["cpu_baseline"] = {"value": None, "error": str(e)}
+            try:
+                out["cpu_baseline_blas"] = cpu_baseline_blas()
+            except Exception as e:
+                out["cpu_baseline_blas"] = {"value": None, "error": str(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
