@@ -262,10 +262,10 @@ def main():
             # inside this process); null when the file is absent
             traffic, tsrc = None, None
             try:
-                if args.dtype != "f32":
-                    raise KeyError("PMC traffic is recorded for the fp32 kernels only")
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = pm["kernels"]["k_policy_bwd<72, 256>"]["hbm_bytes"]
+                traffic = pm["kernels"]["k_policy_bwd<72, 256>" if args.dtype == "f32" else "k_policy_bwd_bf16<72, 256>"]["hbm_bytes"]
+                if MINIBATCH != 4096 or QUADS != 8:
+                    traffic = traffic * (MINIBATCH * (QUADS // 8)) / 4096.0     # the passes sample 4096-tile launches
                 tsrc = "profiles/r01_pmc_traffic.json (" + pm["source"] + ")"
             except Exception:
                 pass
@@ -279,8 +279,12 @@ def main():
                     "vector instruction between MFMAs adds ~2 ns per SIMD: instruction-mix ceiling of this kernel "
                     "(2432 MFMA + ~5250 vector instr per tile) ~125-130 TFLOP/s",
                     "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
-                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (QUADS // 8) * (2 * HID * 32 * 4 + 32 * F + 32 * 16) + 256 * 4 *
-                    (HID * HID + HID * 96 + HID * 6 + 4)}
+                    # per 32-row tile: the two saved activation tiles + state rows + dY in (fp32: 4 B, bf16: 2 B per
+                    # activation; bf16 also writes the dZ1 / X operand fragments of the dW1 kernel); per workgroup one slab out
+                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (QUADS // 8) * (
+                        (2 * HID * 32 * 4 + 32 * F + 32 * 16) if args.dtype == "f32" else
+                        (2 * HID * 32 * 2 + 32 * F + 32 * 16 + HID * 32 * 2 + 96 * 32 * 2)) + 256 * 4 *
+                    (HID * HID + (HID * 96 if args.dtype == "f32" else 0) + HID * 6 + 4)}
     elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
         PPO.synchronize()
