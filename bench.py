@@ -79,6 +79,7 @@ def cpu_baseline_blas():
     import torch
     from oracle import oracle as orc
     from oracle import np_oracle as npo
+    torch.set_num_threads(min(16, os.cpu_count() or 1))        # a one-GPU box's CPU share is 16 cores
     n_env, T, B = 64, 64, 1024
     params = orc.glorot_params(F, HID, 2, seed=0)
     layers = [(torch.tensor(W, dtype=torch.float32, requires_grad=True), torch.tensor(b, dtype=torch.float32, requires_grad=True))
