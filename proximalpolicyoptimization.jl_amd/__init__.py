@@ -881,9 +881,16 @@ class DataParallel:
         t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         assert t.data_ptr() == ptr and t.numel() == n and t.dtype == torch.float32
 
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":          # CPU rehearsal: host round trip (allreduce_)
+            reduce = lambda: self.allreduce_(t)
+        else:                                     # RCCL: one in-place sum on the engine's stream, nothing else per step
+            sum_op = dist.ReduceOp.SUM
+            reduce = lambda: dist.all_reduce(t, op=sum_op)
+
         def hook(ctx, dev_ptr, n_floats):
             try:
-                self.allreduce_(t)
+                reduce()
                 return 0
             except Exception:
                 return 1
