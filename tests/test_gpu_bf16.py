@@ -90,6 +90,29 @@ def test_bf16_rollout_indices_exact_and_env_path(P, orc, npo):
         "returns stay fp32/fp64 and bit-exact in bf16 mode (fp32 GAE)"
 
 
+@pytest.mark.parametrize("HID", [128, 256])
+def test_bf16_rollout_one_launch_equals_per_step(P, HID):
+    """The whole T-step rollout in one launch (MODE 3 of the bf16 forward kernel, env state in LDS) and the three
+    launches per step produce the same columns bit for bit, and leave the env in the same state."""
+    cols = []
+    for persistent in (False, True):
+        P.set_rollout_persistent(persistent)
+        try:
+            env = P.HipVecEnv(num_envs=37, Q=8, max_actions=7, seed=5, global_offset=11)
+            pol = P.HipPolicy(72, HID, 2, 4, seed=9, dtype="bf16")
+            ro = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro, env, pol, 23, 0.99, record_probs=True)
+            st, act = ro.state_data
+            ro2 = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro2, env, pol, 3, 0.99)        # continues from the state the first call left
+            cols.append((st, act, ro.selected_actions, ro.selected_action_probabilities, ro.raw_rewards, ro.terminal,
+                         ro.rewards, ro.full_probs(), ro2.state_data[0], ro2.selected_actions))
+        finally:
+            P.set_rollout_persistent(None)
+    for a, b in zip(*cols):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def _dataset(P, N, T, HID, seed, Q=8):
     env = P.HipVecEnv(num_envs=N, Q=Q, max_actions=12, seed=seed)
     pol = P.HipPolicy(72, HID, 2, 4, seed=seed + 1, dtype="bf16")
