@@ -28,6 +28,9 @@
 #ifndef PPO_BF16_ACT_NT
 #define PPO_BF16_ACT_NT 1
 #endif
+#ifndef PPO_BF16_TMPL_LDS
+#define PPO_BF16_TMPL_LDS 1
+#endif
 #ifndef PPO_BF16_RING_SPREAD
 #define PPO_BF16_RING_SPREAD 1
 #endif
@@ -144,9 +147,17 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
             }
         }
         if (TPS == 1) {
+#if PPO_BF16_TMPL_LDS
+            // the 32 template rows (36 ids each) sit behind the env slots in LDS: nine registers less to carry through
+            // the tile loop (they spilled, and every scratch reload waits on vmcnt behind the rollout-column stores)
+            uint32_t* tl = reinterpret_cast<uint32_t*>(env_lds + (size_t)8 * a.env_slots * slot_bytes);
+            for (int i = tid; i < 32 * PPO_TPL / 4; i += 512) tl[i] = reinterpret_cast<const uint32_t*>(a.env_tmpl)[i];
+            __syncthreads();
+#else
             const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
 #pragma unroll
             for (int k = 0; k < 9; ++k) tmpl_regs[k] = tp[k];
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -178,6 +189,11 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 if (TPS == 1) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) tid9[k] = tmpl_regs[k];
+#if PPO_BF16_TMPL_LDS
+                    const uint32_t* tl = reinterpret_cast<const uint32_t*>(env_lds + (size_t)8 * a.env_slots * slot_bytes) + j * (PPO_TPL / 4);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) tid9[k] = tl[k];
+#endif
                 } else {
                     const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + (32 * ts + j) * PPO_TPL);
 #pragma unroll
@@ -399,7 +415,7 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
     a.env_slots = slots;
     set_fwd_stamps(a);
     a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
-    const size_t env_bytes = (size_t)8 * slots * (2 * V + 32);
+    const size_t env_bytes = (size_t)8 * slots * (2 * V + 32) + 32 * PPO_TPL;      // env slots + the template rows
 #define LAUNCHP(HH, TT)                                                                                              \
     do {                                                                                                             \
         const size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                      \
