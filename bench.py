@@ -320,6 +320,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if use_dist:
+        PPO._lib.lib().ppo_rccl_finalize()         # no-op unless PPO_NATIVE_RCCL=1 created the in-library communicator
         dist.destroy_process_group()
 
 

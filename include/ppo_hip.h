@@ -207,6 +207,17 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
                   const int64_t* perm, uint64_t seed, int32_t world, ppo_allreduce_fn allreduce,
                   void* allreduce_ctx, double* ppo_hist, double* entropy_hist, double* lr_hist);
 
+/* Optional native hook: the same all-reduce as one RCCL call from inside the library, on the engine's stream (no
+ * host-language callback per optimiser step).  RCCL is resolved with dlopen at first use.  The host distributes the
+ * 128-byte unique id between its ranks (rank 0 calls ppo_rccl_unique_id, every rank ppo_rccl_init after
+ * ppo_device_init) and passes ppo_rccl_allreduce as the `allreduce` argument of ppo_train.  Replaces, on the reference
+ * side, nothing: the reference is single-process.  Exercised with one rank on the one-GPU test box
+ * only -- the torch.distributed / Julia hook stays the default of bench.py (PPO_NATIVE_RCCL=1 opts in). */
+int32_t ppo_rccl_unique_id(uint8_t* out128);
+int32_t ppo_rccl_init(int32_t rank, int32_t world, const uint8_t* id128);
+int32_t ppo_rccl_allreduce(void* ctx, void* grad_dev, int64_t n_floats);      /* a ppo_allreduce_fn */
+int32_t ppo_rccl_finalize(void);
+
 /* ---------------------------------------------------------------- out-of-core rollout store
  * DiskRollouts / DiskDataset (src/rollouts_to_disk.jl:1-171, src/dataset.jl:1-82) for rollouts that should not
  * stay resident: while ppo_collect_rollouts runs, every finished step [N] is copied device -> pinned host with

@@ -29,6 +29,7 @@ import ctypes as C
 import functools
 import os
 import shutil
+import sys
 
 import numpy as np
 
@@ -873,6 +874,12 @@ class DataParallel:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         return tensor
 
+    def _native_rccl_hook(self):
+        global _NATIVE_RCCL_HOOK                   # one in-library communicator per process, created on first use
+        if _NATIVE_RCCL_HOOK is False:
+            _NATIVE_RCCL_HOOK = _native_rccl_hook_impl(self.rank, self.world)
+        return _NATIVE_RCCL_HOOK
+
     def make_hook(self, policy):
         import torch
         # the engine must run on the stream torch orders its collectives against
@@ -882,6 +889,10 @@ class DataParallel:
         assert t.data_ptr() == ptr and t.numel() == n and t.dtype == torch.float32
 
         import torch.distributed as dist
+        if os.environ.get("PPO_NATIVE_RCCL") == "1" and dist.get_backend() != "gloo":
+            native = self._native_rccl_hook()
+            if native is not None:
+                return native
         if dist.get_backend() == "gloo":          # CPU rehearsal: host round trip (allreduce_)
             reduce = lambda: self.allreduce_(t)
         else:                                     # RCCL: one in-place sum on the engine's stream, nothing else per step
@@ -895,6 +906,28 @@ class DataParallel:
             except Exception:
                 return 1
         return _lib.ALLREDUCE_FN(hook)
+
+
+_NATIVE_RCCL_HOOK = False                          # False: not tried yet; None: failed (torch hook stays)
+
+
+def _native_rccl_hook_impl(rank, world):
+    """ppo_rccl_* (include/ppo_hip.h): the unique id travels over the host's process group, the all-reduce itself is
+    one RCCL call made by the library on its own stream.  Returns None (torch hook stays) if anything fails."""
+    import torch
+    import torch.distributed as dist
+    try:
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            call("ppo_rccl_unique_id", uid.ctypes.data_as(C.c_void_p))
+        t = torch.from_numpy(uid).cuda()
+        dist.broadcast(t, 0)
+        uid = t.cpu().numpy()
+        call("ppo_rccl_init", int(rank), int(world), uid.ctypes.data_as(C.c_void_p))
+        return _lib.ALLREDUCE_FN(C.cast(_lib.lib().ppo_rccl_allreduce, C.c_void_p).value)
+    except Exception as e:                      # noqa: BLE001 -- any failure: keep the torch.distributed hook
+        sys.stderr.write("PPO_NATIVE_RCCL=1: falling back to the torch.distributed hook (%s)\n" % e)
+        return None
 
 
 # ---------------------------------------------------------------- checkpoints (BSON.@save / BSON.@load of the policy)

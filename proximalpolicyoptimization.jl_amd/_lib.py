@@ -91,6 +91,10 @@ SIGNATURES = {
     "ppo_rollouts_load_disk": [H, C.c_char_p],
     "ppo_average_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
     "ppo_profile_returns": [C.c_int64, C.c_int64, C.c_double, C.c_int32, c_f64p],
+    "ppo_rccl_unique_id": [C.c_void_p],
+    "ppo_rccl_init": [C.c_int32, C.c_int32, C.c_void_p],
+    "ppo_rccl_allreduce": [C.c_void_p, C.c_void_p, C.c_int64],
+    "ppo_rccl_finalize": [],
     "ppo_profile_enable": [C.c_int32],
     "ppo_profile_get": [C.c_char_p, c_f64p, c_i64p],
 }

@@ -85,3 +85,42 @@ def test_two_ranks_one_gpu_stay_in_sync_and_match_the_union(ppo, orc, tmp_path):
     assert np.abs(r0["grad1"] - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
     # and training moved the replicas away from the initial parameters
     assert not np.array_equal(r0["params"], p0) and np.all(np.isfinite(r0["params"]))
+
+
+@pytest.fixture(scope="module")
+def P(ppo):
+    if ppo.device_count() < 1:
+        pytest.fail("no HIP device: the gpu-marked tests must run on the GPU box")
+    return ppo
+
+
+def test_native_rccl_hook_single_rank(P):
+    """ppo_rccl_* (include/ppo_hip.h): a one-rank communicator; the in-library all-reduce is the identity there, so a
+    training run through it must leave exactly the parameters of a run without a hook."""
+    import ctypes as C
+    uid = np.zeros(128, np.uint8)
+    P.call("ppo_rccl_unique_id", uid.ctypes.data_as(C.c_void_p))
+    assert uid.any()
+    P.call("ppo_rccl_init", 0, 1, uid.ctypes.data_as(C.c_void_p))
+
+    class Native:
+        world, force_hook = 1, True
+
+        def make_hook(self, policy):
+            return P._lib.ALLREDUCE_FN(C.cast(P._lib.lib().ppo_rccl_allreduce, C.c_void_p).value)
+
+    try:
+        got = []
+        for par in (None, Native()):
+            env = P.HipVecEnv(num_envs=64, Q=8, max_actions=10, seed=3)
+            pol = P.HipPolicy(72, 128, 2, 4, seed=5)
+            opt = P.Optimiser(P.Adam(1e-3))
+            ro = P.BufferRollouts()
+            P.collect_rollouts_steps_(ro, env, pol, 8, 1.0)
+            perm = np.stack([np.random.default_rng(e).permutation(64 * 8) + 1 for e in range(2)])   # same batches both runs
+            ph, eh, _ = P.ppo_train_(pol, opt, P.construct_dataset(ro), 0.05, 128, 2, 0.01, seed=1, parallel=par,
+                                     perm=perm, verbose=False)
+            got.append((pol.params.copy(), ph, eh))
+        assert np.array_equal(got[0][0], got[1][0]) and got[0][1] == got[1][1] and got[0][2] == got[1][2]
+    finally:
+        P.call("ppo_rccl_finalize")
