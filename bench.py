@@ -138,7 +138,7 @@ def cpu_baseline_blas():
 
 
 def main():
-    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS
+    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS, HID
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -150,6 +150,8 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline line); bf16 = the config-5 arithmetic on the same workload "
                          "(flagged in the output, not the headline)")
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default 4096 = the headline workload)")
+    ap.add_argument("--hid", type=int, choices=[128, 256], default=HID,
+                    help="hidden width: 256 = the headline 2x256 MLP, 128 = the reference's own Policy(72,128,2,4) (not the headline)")
     ap.add_argument("--quads", type=int, choices=[8, 32], default=QUADS,
                     help="quad slots per env: 8 = the headline rand-poly shape (A=128), 32 = the square-mesh-sized action "
                          "space of BASELINE config 4 (A=512, variable-length masked episodes; flagged in the output)")
@@ -159,7 +161,8 @@ def main():
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
-    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS)
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS) or (args.hid != HID)
+    HID = args.hid
     QUADS = args.quads
     N_ENVS = MINIBATCH = args.envs
 
@@ -298,9 +301,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=%d,H=%d,A=%d,F=72 int8), "
-                                   "2x256 MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
+                                   "2x%d MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
                                    "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)"
-                                   % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
+                                   % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, HID, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world},
