@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int PFW = (PPO_FWD_PF < HID / 8) ? PPO_FWD_PF : HID / 8;     // at most the groups of one output tile
     constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : 4;   // weight-fragment groups kept in flight per wave
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
+    static_assert(PF * 64 * 4 <= PPO_PACK_PAD, "the ring reads PF groups past the end of a packed weight stream: padding must cover it");
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;           // half-edge row inside the tile
     const int h = lane >> 5;           // lane half = k parity of the MFMA step
