@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #define PPO_FWD_OUNROLL 1
 #endif
     constexpr int PFW = (PPO_FWD_PF < HID / 8) ? PPO_FWD_PF : HID / 8;     // at most the groups of one output tile
-    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : 4;   // weight-fragment groups kept in flight per wave
+    // two waves per SIMD (HID = 128, F = 72): 4 groups cover the L2 latency; the train forward, whose activation stores
+    // sit in the same vmcnt queue, wants the deep ring here too (0.072 -> 0.069 ms), the rollout does not (8.3 -> 8.7 ms)
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : ((MODE == 2) ? PFW : 4);   // weight-fragment groups kept in flight per wave
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     static_assert(PF * 64 * 4 <= PPO_PACK_PAD, "the ring reads PF groups past the end of a packed weight stream: padding must cover it");
     const int lane = threadIdx.x & 63;
