@@ -7,14 +7,19 @@ epochs of minibatch updates (forward + loss + backward + Adam) over all N*T tran
 Workload (BASELINE configs[1], survey-chosen sizes SURVEY.md 8(d)): 4096 synthetic rand-poly-shaped envs
 (Q=8 -> H=32 half-edges, A=128 actions, F=72 int8 features), policy Dense(72,256)->Dense(256,256)->Dense(256,4)
 fp32, T=128, E=4 epochs, minibatch 4096 per GPU, gamma=1.0, eps=0.05, entropy weight 0.01, Adam 1e-4.
-Multi-GPU (one process per GPU, torchrun): 4096 envs PER GPU (weak scaling), one RCCL all-reduce of the flat
-gradient per optimiser step; no other exchange.
+Multi-GPU (one process per GPU): `python bench.py --gpus N` starts its N rank processes ITSELF (before anything touches
+the GPU) unless a launcher (torchrun) already did.  Headline = weak scaling (BASELINE config 3): 4096 envs and a
+4096-sample minibatch PER GPU, one RCCL all-reduce of the flat gradient per optimiser step (issued by the library
+itself, ppo_rccl_*), no other exchange.  For N > 1 the same JSON line also carries a "strong" object: 4096 envs and a
+4096-sample global minibatch split over the N GPUs, timed the same way.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +33,7 @@ QUADS = 8                             # quad slots per env: H = 4*QUADS half-edg
 GAMMA, EPS, ENT_W, LR = 1.0, 0.05, 0.01, 1e-4
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--dtype bf16 runs only)
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # tools/pmc_traffic.py: measured HBM bytes per launch, keyed by launch shape
 
 
 def flops_per_state(kind):
@@ -71,7 +77,7 @@ def cpu_baseline():
                       "minibatch %d, 2x256 MLP, %.1f s on 1 core" % (n_env, T, EPOCHS, B, dt)}
 
 
-def cpu_baseline_blas():
+def cpu_baseline_blas(threads=None):
     """Second CPU figure, closer to what the Julia reference does on a host: the same path with the Dense products and
     their gradients on the host BLAS / autograd (torch CPU, Float32, all threads) instead of the scalar C restatement --
     serial per-env forward + sample + step! in the rollout (src/collect_rollouts.jl:1-24), batched minibatch step
@@ -79,8 +85,8 @@ def cpu_baseline_blas():
     import torch
     from oracle import oracle as orc
     from oracle import np_oracle as npo
-    torch.set_num_threads(min(16, os.cpu_count() or 1))        # a one-GPU box's CPU share is 16 cores
-    n_env, T, B = 64, 64, 1024
+    torch.set_num_threads(threads or min(16, os.cpu_count() or 1))   # a one-GPU box's CPU share is 16 cores
+    n_env, T, B = (64, 64, 1024) if threads != 1 else (32, 32, 256)
     params = orc.glorot_params(F, HID, 2, seed=0)
     layers = [(torch.tensor(W, dtype=torch.float32, requires_grad=True), torch.tensor(b, dtype=torch.float32, requires_grad=True))
               for (W, b) in npo.unpack_params(params, F, HID, 2)]
@@ -137,6 +143,86 @@ def cpu_baseline_blas():
                       "minibatch %d, %.1f s on %d threads" % (n_env, T, EPOCHS, B, dt, torch.get_num_threads())}
 
 
+def cpu_baseline_all_cores():
+    """the restatement on all host cores -- one replica of the 1-core sample per thread, each on
+    its own env shard (the C restatement releases the GIL), no gradient exchange between them: an upper bound on what
+    partitioning the env batch over `cores` threads can give."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    cores = min(os.cpu_count() or 1, 16)                      # a one-GPU box's CPU share is 16 cores
+    n_env, T, B = 2, 32, 32
+
+    def replica(k):
+        params = orc.glorot_params(F, HID, 2, seed=0)
+        env = orc.Env(Q=8, max_actions=T_STEPS, N=n_env, seed=1234, global_offset=k * n_env)
+        env.reset()
+        ro = orc.collect_rollouts_tn(env, params, HID, T, mode_dev=False)
+        ret = orc.compute_returns_tn(ro["rewards"], ro["done"], GAMMA)
+        M = n_env * T
+        st, act, a0 = ro["states"].reshape(M, 32, F), ro["active"].reshape(M), ro["actions"].reshape(M)
+        po, adv = ro["p_sel"].reshape(M), ret.reshape(M)
+        m, v, bp = np.zeros_like(params), np.zeros_like(params), np.array([0.9, 0.999])
+        rng = np.random.default_rng(k)
+        for _ in range(EPOCHS):
+            perm = rng.permutation(M)
+            for s0 in range(0, M, B):
+                sel = perm[s0:s0 + B]
+                g, _, _ = orc.step_batch_grad_f64(params, F, HID, st[sel], act[sel], a0[sel], po[sel], adv[sel], EPS, ENT_W)
+                orc.adam_step(params, g.astype(np.float32), m, v, bp, LR)
+        return M
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(replica, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "CPU restatement, %d independent replicas (one thread each, own env shard, no gradient exchange) of "
+                      "%d envs x %d steps, %d epochs, minibatch %d, %.1f s" % (cores, n_env, T, EPOCHS, B, dt)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes here, one per GPU.  This parent never
+    touches the GPU (no HIP call, no torch.cuda call), so nothing is exec'ed from a GPU-initialised process.  Rank 0's
+    stdout is forwarded (the one JSON line); any rank failing ends the others and the run exits non-zero."""
+    import tempfile
+    port = _free_port()
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr.fileno()))
+        deadline = time.time() + float(os.environ.get("PPO_BENCH_LAUNCH_TIMEOUT", "1500"))
+        rc = 0
+        while any(p.poll() is None for p in procs):
+            failed = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if failed or time.time() > deadline:
+                rc = failed[0] if failed else 124
+                for p in procs:                               # end exactly the processes started above
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.1)
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode("utf-8", "replace"))
+        sys.stdout.flush()
+    if rc:
+        sys.stderr.write("bench.py: a rank process failed (exit %d); no multi-GPU figure was produced\n" % rc)
+    return rc
+
+
 def main():
     global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS, HID
     ap = argparse.ArgumentParser()
@@ -166,15 +252,22 @@ def main():
     QUADS = args.quads
     N_ENVS = MINIBATCH = args.envs
 
+    # ---- ranks: a launcher's (torchrun) environment wins; otherwise --gpus N > 1 starts the N ranks itself
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    if args.scaling == "strong":
-        if N_ENVS % world:
-            raise SystemExit("--scaling strong needs the env count to divide by the number of GPUs")
-        N_ENVS = MINIBATCH = N_ENVS // world
+    args.gpus = world
+    if N_ENVS % world:
+        raise SystemExit("the env count must divide by the number of GPUs (strong-scaling leg)")
+    # rehearsal switches (tests): PPO_BENCH_BACKEND=gloo runs the exchange over gloo (host round trip of the gradient
+    # buffer), PPO_BENCH_SHARE_GPU=1 puts every rank on device 0 (a one-GPU box), PPO_BENCH_DRYRUN=1 exercises the rank
+    # launch, the rendezvous and the report only (no GPU at all: the CPU test of the launcher)
+    backend = os.environ.get("PPO_BENCH_BACKEND", "nccl")
+    share_gpu = os.environ.get("PPO_BENCH_SHARE_GPU") == "1"
+    dry = os.environ.get("PPO_BENCH_DRYRUN") == "1"
+    dev_index = 0 if share_gpu else local_rank
 
     import ctypes as C
     import ppo_amd as PPO
@@ -186,26 +279,32 @@ def main():
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        kw = {}
+        if not dry:
+            torch.cuda.set_device(dev_index)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", dev_index)
         if "MASTER_ADDR" in os.environ:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, **kw)
         else:
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
-                                    device_id=torch.device("cuda", local_rank))
-    PPO._lib.call("ppo_device_init", local_rank)
+            dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1, **kw)
+        if dist.get_world_size() != world:
+            raise SystemExit("process group size %d != WORLD_SIZE %d" % (dist.get_world_size(), world))
+    if dry:
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "env-steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs, 1/2/4/8 MI355X",
+                              "value": None, "unit": "env-steps/s", "n_gpus": dist.get_world_size(), "dry_run": True,
+                              "steps": args.steps, "warmup": args.warmup}))
+        dist.destroy_process_group()
+        return 0
+    PPO._lib.call("ppo_device_init", dev_index)
     if use_dist:
         PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     dp = PPO.DataParallel(rank, world, force_hook=use_dist)
-    env = PPO.HipVecEnv(num_envs=N_ENVS, Q=QUADS, max_actions=T_STEPS, seed=1234, global_offset=rank * N_ENVS)
     pol = PPO.HipPolicy(F, HID, 2, 4, seed=0, dtype=args.dtype)
     opt = PPO.Optimiser(PPO.Adam(LR))
-    ro = PPO.BufferRollouts()
-
-    def iteration(i):
-        PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
-        ds = PPO.construct_dataset(ro)
-        PPO.ppo_train_(pol, opt, ds, EPS, MINIBATCH, EPOCHS, ENT_W, seed=1000 + i, parallel=dp, verbose=False)
 
     def sync():
         PPO.synchronize()
@@ -214,18 +313,34 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        iteration(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        iteration(args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_run(n_envs, minibatch, seed_base):
+        """W warm-up + K timed PPO iterations on `n_envs` envs per rank; returns (max-over-ranks seconds, iteration fn)."""
+        env = PPO.HipVecEnv(num_envs=n_envs, Q=QUADS, max_actions=T_STEPS, seed=1234, global_offset=rank * n_envs)
+        ro = PPO.BufferRollouts()
+
+        def iteration(i):
+            PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
+            ds = PPO.construct_dataset(ro)
+            PPO.ppo_train_(pol, opt, ds, EPS, minibatch, EPOCHS, ENT_W, seed=seed_base + i, parallel=dp, verbose=False)
+
+        for i in range(args.warmup):
+            iteration(i)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            iteration(args.warmup + i)
+        sync()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, iteration
+
+    strong_requested = args.scaling == "strong"
+    if strong_requested:                                 # the whole line is the strong-scaling figure
+        N_ENVS = MINIBATCH = N_ENVS // world
+    dt, iteration = timed_run(N_ENVS, MINIBATCH, 1000)
 
     # ---- roofline leg: per-kernel HIP-event durations of one more iteration (outside the timed region)
     roof, kernels = None, {}
@@ -245,7 +360,8 @@ def main():
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
                                  "frac": round(tf / peak, 4)}
-        for name in ("k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam"):
+        for name in ("k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
+                     "k_reduce_adam", "allreduce"):
             ms, n = PPO.profile_get(name)
             if n:
                 kernels[name] = {"avg_ms": round(ms / n, 4), "launches": n}
@@ -263,16 +379,18 @@ def main():
         k = kernels.get("k_policy_bwd")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
-            # inside this process); null when the file is absent
+            # inside this process); null when no pass was made for this exact launch shape
             traffic, tsrc = None, None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = pm["kernels"]["k_policy_bwd<72, 256>" if args.dtype == "f32" else "k_policy_bwd_bf16<72, 256>"]["hbm_bytes"]
-                if MINIBATCH != 4096 or QUADS != 8:
-                    traffic = traffic * (MINIBATCH * (QUADS // 8)) / 4096.0     # the passes sample 4096-tile launches
-                tsrc = "profiles/r01_pmc_traffic.json (" + pm["source"] + ")"
+                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+                key = "%s|envs=%d|quads=%d|hid=%d" % (args.dtype, MINIBATCH, QUADS, HID)
+                ent = pm["launch_shapes"].get(key)
+                if ent:
+                    traffic = ent["k_policy_bwd_hbm_bytes"]
+                    tsrc = "profiles/%s [%s] (%s)" % (PMC_TRAFFIC_FILE, key, pm["source"])
             except Exception:
                 pass
+            tiles = MINIBATCH * (QUADS // 8)
             roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
@@ -283,21 +401,35 @@ def main():
                     "vector instruction between MFMAs adds ~2 ns per SIMD: instruction-mix ceiling of this kernel "
                     "(2432 MFMA + ~5250 vector instr per tile) ~125-130 TFLOP/s",
                     "algorithmic_flop_per_launch": flops_per_state("bwd") * MINIBATCH,
-                    # per 32-row tile: the two saved activation tiles + state rows + dY in (fp32: 4 B, bf16: 2 B per
-                    # activation; bf16 also writes the dZ1 / X operand fragments of the dW1 kernel); per workgroup one slab out
-                    "algorithmic_hbm_bytes_per_launch": MINIBATCH * (QUADS // 8) * (
-                        (2 * HID * 32 * 4 + 32 * F + 32 * 16) if args.dtype == "f32" else
-                        (2 * HID * 32 * 2 + 32 * F + 32 * 16 + HID * 32 * 2 + 96 * 32 * 2)) + 256 * 4 *
-                    (HID * HID + (HID * 96 if args.dtype == "f32" else 0) + HID * 6 + 4)}
+                    # TRUE minimum of the backward per launch: per 32-row tile the two saved activation tiles, the state
+                    # rows and dY in (fp32: 4 B, bf16: 2 B per activation), ONE gradient out.  The per-workgroup gradient
+                    # slabs (written here, re-read by the reduction) are design traffic and listed separately.
+                    "algorithmic_hbm_bytes_per_launch": tiles * (2 * HID * 32 * (4 if args.dtype == "f32" else 2) + 32 * F + 32 * 16)
+                    + 4 * (HID * HID + HID * F + HID * 6 + 4),
+                    "design_hbm_bytes_per_launch": {"gradient_slabs_written": min(256, tiles) * 4 * (HID * HID + HID * 96 + HID * 6 + 4)}}
     elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
         PPO.synchronize()
 
+    # ---- strong-scaling leg (N > 1): the 4096 envs and the 4096-sample global minibatch split over the ranks
+    strong = None
+    if world > 1 and not strong_requested:
+        sdt, _ = timed_run(N_ENVS // world, MINIBATCH // world, 5000)
+        strong = {"value": N_ENVS * T_STEPS * args.steps / sdt, "unit": "env-steps/s", "ms_per_step": sdt / args.steps * 1e3,
+                  "envs_total": N_ENVS, "envs_per_gpu": N_ENVS // world, "minibatch_global": MINIBATCH,
+                  "minibatch_per_gpu": MINIBATCH // world,
+                  "note": "same workload as n_gpus=1 (4096 envs, global minibatch 4096) split over the ranks; "
+                          "strong-scaling efficiency = this value / (n_gpus x the n_gpus=1 value)"}
+
     if rank == 0:
+        comm = PPO.rccl_comm_info() if use_dist else None
         value = world * N_ENVS * T_STEPS * args.steps / dt
         out = {
             "metric": "env-steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs, 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s",
+            # read back from the communicator, not from the launcher's environment
+            "n_gpus": (comm[1] if comm else (dist.get_world_size() if use_dist else 1)),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=%d,H=%d,A=%d,F=72 int8), "
@@ -307,25 +439,27 @@ def main():
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world},
+            "allreduce": (dp.hook_kind if use_dist else None), "rccl_ranks": (comm[1] if comm else None),
+            "strong": strong,
             "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced, "headline_config": not nonheadline,
             "target_frac_of_1e6": value / 1e6,
         }
         if not args.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline()
-            except Exception as e:      # the oracle is only a reported baseline
-                out["cpu_baseline"] = {"value": None, "error": str(e)}
-            try:
-                out["cpu_baseline_blas"] = cpu_baseline_blas()
-            except Exception as e:
-                out["cpu_baseline_blas"] = {"value": None, "error": str(e)}
+            for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_blas", cpu_baseline_blas),
+                            ("cpu_baseline_blas_1core", lambda: cpu_baseline_blas(threads=1)),
+                            ("cpu_baseline_all_cores", cpu_baseline_all_cores)):
+                try:
+                    out[key] = fn()
+                except Exception as e:      # the oracle is only a reported baseline
+                    out[key] = {"value": None, "error": str(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if use_dist:
-        PPO._lib.lib().ppo_rccl_finalize()         # no-op unless PPO_NATIVE_RCCL=1 created the in-library communicator
+        PPO._lib.lib().ppo_rccl_finalize()         # no-op unless the in-library communicator was created
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -142,6 +142,12 @@ int32_t ppo_adam_get_lr(ppo_adam_t opt, double* eta);                    /* get_
 int32_t ppo_adam_set_lr(ppo_adam_t opt, double eta);
 int32_t ppo_adam_get_state(ppo_adam_t opt, float* m, float* v, double* beta_pow2);
 int32_t ppo_adam_set_state(ppo_adam_t opt, const float* m, const float* v, const double* beta_pow2);
+/* number of epochs this optimiser has trained through ppo_train.  Together with the caller's seed it keys the device
+ * minibatch permutation (the stand-in for randperm, src/train.jl:93), so there is no hidden process-global state: the
+ * same seed with a fresh optimiser reproduces a run, and a checkpointed optimiser (m, v, beta powers, epoch count)
+ * resumes one. */
+int32_t ppo_adam_get_epoch_count(ppo_adam_t opt, int64_t* epochs);
+int32_t ppo_adam_set_epoch_count(ppo_adam_t opt, int64_t epochs);
 
 /* ---------------------------------------------------------------- rollout buffer */
 /* BufferRollouts()                                          src/rollout_buffer.jl:1-22 */
@@ -198,24 +204,31 @@ int32_t ppo_step_batch(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro,
 typedef int32_t (*ppo_allreduce_fn)(void* ctx, void* grad_dev, int64_t n_floats);
 /* ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight)
  *                                                          src/train.jl:86-153
- * perm: NULL -> device Feistel permutation keyed by (seed, epoch counter), else num_epochs
+ * perm: NULL -> device Feistel permutation keyed by (seed, ppo_adam_get_epoch_count), else num_epochs
  * explicit 0-based permutations of length len (randperm, :93).  hist arrays have num_epochs
  * entries: mean per-batch losses and the learning rate (:127,144-150).
- * world = data-parallel ranks (minibatch per rank = batch_size, global = world*batch_size). */
-int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon,
-                  int64_t batch_size, int32_t num_epochs, double entropy_weight, int32_t adv_mode,
-                  const int64_t* perm, uint64_t seed, int32_t world, ppo_allreduce_fn allreduce,
-                  void* allreduce_ctx, double* ppo_hist, double* entropy_hist, double* lr_hist);
+ * Data parallel: rank / world = this process's place among the ranks that each hold an env shard (1 process: 0 / 1).
+ * The minibatch of a step is the union of `batch_size` samples per rank.  Shards may differ in length: the ranks
+ * exchange their dataset lengths once per call (through the hook), all run max_r ceil(len_r / batch_size) steps per
+ * epoch, each step's gradient is the exact mean over the samples all ranks contributed to it, and a rank whose shard
+ * is exhausted contributes zeros -- so every rank issues the same sequence of collectives.  batch_size must not
+ * exceed the shortest shard (the reference's @assert, on every rank alike). */
+int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon, int64_t batch_size,
+                  int32_t num_epochs, double entropy_weight, int32_t adv_mode, const int64_t* perm, uint64_t seed,
+                  int32_t rank, int32_t world, ppo_allreduce_fn allreduce, void* allreduce_ctx, double* ppo_hist,
+                  double* entropy_hist, double* lr_hist);
 
-/* Optional native hook: the same all-reduce as one RCCL call from inside the library, on the engine's stream (no
- * host-language callback per optimiser step).  RCCL is resolved with dlopen at first use.  The host distributes the
- * 128-byte unique id between its ranks (rank 0 calls ppo_rccl_unique_id, every rank ppo_rccl_init after
- * ppo_device_init) and passes ppo_rccl_allreduce as the `allreduce` argument of ppo_train.  Replaces, on the reference
- * side, nothing: the reference is single-process.  Exercised with one rank on the one-GPU test box
- * only -- the torch.distributed / Julia hook stays the default of bench.py (PPO_NATIVE_RCCL=1 opts in). */
+/* Native hook (the default of bench.py and DataParallel): the same all-reduce as ONE RCCL call made by the library
+ * itself on the engine's stream -- no host-language callback per optimiser step.  RCCL is resolved with dlopen at first
+ * use (a host that already carries an RCCL, e.g. torch, shares its copy).  The engine owns no rendezvous: the host
+ * distributes the 128-byte unique id between its ranks (rank 0 calls ppo_rccl_unique_id, every rank ppo_rccl_init
+ * after ppo_device_init), runs ppo_rccl_self_test collectively, and passes ppo_rccl_allreduce as the `allreduce`
+ * argument of ppo_train.  Replaces, on the reference side, nothing: the reference is single-process. */
 int32_t ppo_rccl_unique_id(uint8_t* out128);
 int32_t ppo_rccl_init(int32_t rank, int32_t world, const uint8_t* id128);
 int32_t ppo_rccl_allreduce(void* ctx, void* grad_dev, int64_t n_floats);      /* a ppo_allreduce_fn */
+int32_t ppo_rccl_comm_info(int32_t* rank, int32_t* world);                    /* as the communicator reports them */
+int32_t ppo_rccl_self_test(int32_t* ok);                                      /* collective: known-answer all-reduce */
 int32_t ppo_rccl_finalize(void);
 
 /* ---------------------------------------------------------------- out-of-core rollout store

@@ -772,26 +772,27 @@ def ppo_train_(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entr
     adam = optimizer._adam()
     oh = adam._bind(policy)
     n = len(dataset)
-    if not (1 <= batch_size <= n):
-        raise PPOError(-1, "AssertionError: 1 <= batch_size <= num_data")                    # :88
     pp = None
     if perm is not None:
         pp = np.ascontiguousarray(np.asarray(perm, np.int64).reshape(num_epochs, n) - 1)
     ph, eh, lh = (np.zeros(num_epochs, np.float64) for _ in range(3))
-    world, fn, keep = 1, _lib.ALLREDUCE_FN(0), None
+    rank, world, fn, keep = 0, 1, _lib.ALLREDUCE_FN(0), None
     if parallel is not None and (parallel.world > 1 or parallel.force_hook):
-        world = parallel.world
+        rank, world = parallel.rank, parallel.world
         keep = parallel.make_hook(policy)
         fn = keep
+    # the data-parallel shards may differ in length: the batch_size assert is then made inside ppo_train on the
+    # shortest shard, identically on every rank (a local raise here would leave the other ranks in a collective)
+    if world == 1 and not (1 <= batch_size <= n):
+        raise PPOError(-1, "AssertionError: 1 <= batch_size <= num_data")                    # :88
     call("ppo_train", policy._h, oh, dataset.rollouts._h, float(epsilon), int(batch_size), int(num_epochs),
          float(entropy_weight), _adv_mode(advantage), _p(pp, _lib.c_i64p) if pp is not None else None, int(seed),
-         int(world), fn, None,
+         int(rank), int(world), fn, None,
          _p(ph, _lib.c_f64p), _p(eh, _lib.c_f64p), _p(lh, _lib.c_f64p))
-    lr = get_optimizer_learning_rate(optimizer)
     if verbose:
         for e in range(num_epochs):                                                         # :146
-            print("EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e" % (e + 1, ph[e], eh[e], lr))
-    return list(ph), list(eh), [lr] * num_epochs
+            print("EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e" % (e + 1, ph[e], eh[e], lh[e]))
+    return list(ph), list(eh), list(lh)                     # lr = get_optimizer_learning_rate per epoch (:144)
 
 
 def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size, num_ppo_iterations, evaluator,
@@ -812,10 +813,7 @@ def ppo_iterate_(policy, env, optimizer, episodes_per_iteration, minibatch_size,
         loss["ppo"] += p
         loss["entropy"] += e
         loss["lr"] += lr
-        try:
-            save_loss(evaluator, loss)                                                       # :196,247
-        except PPOError:
-            pass                         # no save_loss method exists anywhere in the reference (Appendix B)
+        save_loss(evaluator, loss)       # :196,247 -- like the reference, an evaluator without a save_loss method throws
     if state_data_path is not None and os.path.isdir(state_data_path):
         if verbose:
             print("\n\nCLEARING DATA IN ROLLOUTS FOLDER :")                                 # :199
@@ -853,6 +851,7 @@ class DataParallel:
     def __init__(self, rank=0, world=1, force_hook=False):
         self.rank, self.world = int(rank), int(world)
         self.force_hook = bool(force_hook)      # exercise the all-reduce hook even with one rank (tests)
+        self.hook_kind = None                   # set by make_hook: "native-rccl" or "torch.distributed/<backend>"
 
     def env_shard(self, total_envs):
         """Contiguous shard [offset, offset+n) of this rank; RNG uses global env ids."""
@@ -881,53 +880,102 @@ class DataParallel:
         return _NATIVE_RCCL_HOOK
 
     def make_hook(self, policy):
+        """The ppo_allreduce_fn handed to ppo_train.  Default: the library's own RCCL all-reduce (ppo_rccl_*), adopted
+        only if EVERY rank brought its communicator up and passed the known-answer all-reduce (the decision is itself
+        collective, so the ranks can never end up on different collectives); otherwise -- or with PPO_NATIVE_RCCL=0, or
+        on the gloo rehearsal backend -- one torch.distributed all-reduce per step on a tensor aliasing the buffer."""
         import torch
+        import torch.distributed as dist
         # the engine must run on the stream torch orders its collectives against
         call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
         ptr, n = policy.grad_buffer_dev()
-        t = torch.as_tensor(_DevArray(ptr, n), device="cuda")
-        assert t.data_ptr() == ptr and t.numel() == n and t.dtype == torch.float32
-
-        import torch.distributed as dist
-        if os.environ.get("PPO_NATIVE_RCCL") == "1" and dist.get_backend() != "gloo":
+        if os.environ.get("PPO_NATIVE_RCCL", "1") != "0" and dist.get_backend() != "gloo":
             native = self._native_rccl_hook()
             if native is not None:
+                self.hook_kind = "native-rccl"
                 return native
-        if dist.get_backend() == "gloo":          # CPU rehearsal: host round trip (allreduce_)
-            reduce = lambda: self.allreduce_(t)
-        else:                                     # RCCL: one in-place sum on the engine's stream, nothing else per step
-            sum_op = dist.ReduceOp.SUM
-            reduce = lambda: dist.all_reduce(t, op=sum_op)
+        self.hook_kind = "torch.distributed/" + dist.get_backend()
+
+        views = {}
+
+        def reduce(dev_ptr, n_floats):             # also serves ppo_train's small shard-length exchange
+            t = views.get((dev_ptr, n_floats)) if dev_ptr == ptr else None
+            if t is None:
+                t = torch.as_tensor(_DevArray(dev_ptr, n_floats), device="cuda")
+                if dev_ptr == ptr:                 # the gradient buffer lives as long as the policy: keep its view
+                    views[(dev_ptr, n_floats)] = t
+            self.allreduce_(t)
 
         def hook(ctx, dev_ptr, n_floats):
             try:
-                reduce()
+                reduce(dev_ptr, n_floats)
                 return 0
-            except Exception:
+            except Exception:                      # noqa: BLE001 -- reported through the status code
                 return 1
         return _lib.ALLREDUCE_FN(hook)
 
 
-_NATIVE_RCCL_HOOK = False                          # False: not tried yet; None: failed (torch hook stays)
+_NATIVE_RCCL_HOOK = False                          # False: not tried yet; None: not adopted (torch hook stays)
 
 
 def _native_rccl_hook_impl(rank, world):
     """ppo_rccl_* (include/ppo_hip.h): the unique id travels over the host's process group, the all-reduce itself is
-    one RCCL call made by the library on its own stream.  Returns None (torch hook stays) if anything fails."""
+    one RCCL call made by the library on its own stream.  Every stage is followed by a MIN all-reduce of a success
+    flag over the host group, and rank 0 always reaches the broadcast (sending a zero id if it could not make one):
+    either all ranks adopt the native communicator or all of them keep the torch.distributed hook."""
     import torch
     import torch.distributed as dist
-    try:
-        uid = np.zeros(128, np.uint8)
-        if rank == 0:
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    why = ""
+    uid = np.zeros(128, np.uint8)
+    if rank == 0:
+        try:
             call("ppo_rccl_unique_id", uid.ctypes.data_as(C.c_void_p))
-        t = torch.from_numpy(uid).cuda()
-        dist.broadcast(t, 0)
-        uid = t.cpu().numpy()
-        call("ppo_rccl_init", int(rank), int(world), uid.ctypes.data_as(C.c_void_p))
-        return _lib.ALLREDUCE_FN(C.cast(_lib.lib().ppo_rccl_allreduce, C.c_void_p).value)
-    except Exception as e:                      # noqa: BLE001 -- any failure: keep the torch.distributed hook
-        sys.stderr.write("PPO_NATIVE_RCCL=1: falling back to the torch.distributed hook (%s)\n" % e)
+        except Exception as e:                  # noqa: BLE001
+            uid[:] = 0
+            why = str(e)
+    t = torch.from_numpy(uid).cuda()
+    dist.broadcast(t, 0)
+    uid = np.ascontiguousarray(t.cpu().numpy())
+    ok = bool(uid.any())
+    if ok:
+        try:
+            call("ppo_rccl_init", int(rank), int(world), uid.ctypes.data_as(C.c_void_p))
+        except Exception as e:                  # noqa: BLE001
+            ok, why = False, str(e)
+    if all_ok(ok):
+        try:                                    # collective known-answer all-reduce on the new communicator
+            good = C.c_int32(0)
+            call("ppo_rccl_self_test", C.byref(good))
+            r_, w_ = C.c_int32(-1), C.c_int32(-1)
+            call("ppo_rccl_comm_info", C.byref(r_), C.byref(w_))
+            ok = bool(good.value) and r_.value == rank and w_.value == world
+            if not ok:
+                why = "known-answer all-reduce / communicator size check failed"
+        except Exception as e:                  # noqa: BLE001
+            ok, why = False, str(e)
+        if all_ok(ok):
+            return _lib.ALLREDUCE_FN(C.cast(_lib.lib().ppo_rccl_allreduce, C.c_void_p).value)
+    try:
+        lib().ppo_rccl_finalize()
+    except Exception:                           # noqa: BLE001
+        pass
+    sys.stderr.write("rank %d: native RCCL hook not adopted (%s); every rank uses the torch.distributed hook\n"
+                     % (rank, why or "another rank failed"))
+    return None
+
+
+def rccl_comm_info():
+    """(rank, world) as the library's own communicator reports them, or None when the native hook is not in use."""
+    r_, w_ = C.c_int32(-1), C.c_int32(-1)
+    if lib().ppo_rccl_comm_info(C.byref(r_), C.byref(w_)) != 0:
         return None
+    return r_.value, w_.value
 
 
 # ---------------------------------------------------------------- checkpoints (BSON.@save / BSON.@load of the policy)

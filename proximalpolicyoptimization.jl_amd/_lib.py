@@ -64,6 +64,8 @@ SIGNATURES = {
     "ppo_adam_set_lr": [H, C.c_double],
     "ppo_adam_get_state": [H, c_f32p, c_f32p, c_f64p],
     "ppo_adam_set_state": [H, c_f32p, c_f32p, c_f64p],
+    "ppo_adam_get_epoch_count": [H, c_i64p],
+    "ppo_adam_set_epoch_count": [H, C.c_int64],
     "ppo_rollouts_create": [H, C.c_int64, HP],
     "ppo_rollouts_destroy": [H],
     "ppo_rollouts_len": [H, c_i64p],
@@ -85,7 +87,7 @@ SIGNATURES = {
     "ppo_last_losses": [H, c_f64p, c_f64p],
     "ppo_step_batch": [H, H, H, c_i64p, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p, c_f64p],
     "ppo_train": [H, H, H, C.c_double, C.c_int64, C.c_int32, C.c_double, C.c_int32, c_i64p, C.c_uint64, C.c_int32,
-                  ALLREDUCE_FN, C.c_void_p, c_f64p, c_f64p, c_f64p],
+                  C.c_int32, ALLREDUCE_FN, C.c_void_p, c_f64p, c_f64p, c_f64p],
     "ppo_rollouts_attach_disk": [H, C.c_char_p, C.c_int32],
     "ppo_rollouts_detach_disk": [H],
     "ppo_rollouts_load_disk": [H, C.c_char_p],
@@ -94,6 +96,8 @@ SIGNATURES = {
     "ppo_rccl_unique_id": [C.c_void_p],
     "ppo_rccl_init": [C.c_int32, C.c_int32, C.c_void_p],
     "ppo_rccl_allreduce": [C.c_void_p, C.c_void_p, C.c_int64],
+    "ppo_rccl_comm_info": [c_i32p, c_i32p],
+    "ppo_rccl_self_test": [c_i32p],
     "ppo_rccl_finalize": [],
     "ppo_profile_enable": [C.c_int32],
     "ppo_profile_get": [C.c_char_p, c_f64p, c_i64p],

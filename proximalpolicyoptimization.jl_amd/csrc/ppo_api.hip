@@ -3,6 +3,7 @@
 // in the kernels).  There is NO CPU fallback: every entry point runs on the GPU or fails.
 #include "ppo_internal.h"
 #include "ppo_device.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -70,7 +71,7 @@ static int32_t d2h(T* dst, const T* src, size_t n) {
 
 extern "C" {
 
-int32_t ppo_version(void) { return 100; }
+int32_t ppo_version(void) { return 200; }
 
 int32_t ppo_last_error(char* buf, int64_t cap) {
     if (!buf || cap <= 0) return PPO_ERR_ARG;
@@ -429,6 +430,9 @@ int32_t ppo_adam_set_state(ppo_adam_t opt, const float* m, const float* v, const
     return PPO_OK;
 }
 
+int32_t ppo_adam_get_epoch_count(ppo_adam_t opt, int64_t* epochs) { ARG_CHECK(opt && epochs, "null"); *epochs = opt->epochs_done; return PPO_OK; }
+int32_t ppo_adam_set_epoch_count(ppo_adam_t opt, int64_t epochs) { ARG_CHECK(opt && epochs >= 0, "bad epoch count"); opt->epochs_done = epochs; return PPO_OK; }
+
 // ================================================================ rollouts
 static int32_t rollouts_reserve(ppo_rollouts_s* r, int64_t T) {
     if (T <= r->capT) return PPO_OK;
@@ -736,23 +740,41 @@ __global__ void k_perm_index(const int32_t* __restrict__ index, const int64_t* _
 
 int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double epsilon, int64_t batch_size,
                   int32_t num_epochs, double entropy_weight, int32_t adv_mode, const int64_t* perm, uint64_t seed,
-                  int32_t world, ppo_allreduce_fn allreduce, void* allreduce_ctx, double* ppo_hist,
+                  int32_t rank, int32_t world, ppo_allreduce_fn allreduce, void* allreduce_ctx, double* ppo_hist,
                   double* entropy_hist, double* lr_hist) {
     ARG_CHECK(pol && opt && ro && opt->pol == pol, "ppo_train!: null/mismatched argument");
     const int64_t len = ro->len;
-    ARG_CHECK(1 <= batch_size && batch_size <= len, "1 <= batch_size <= num_data (src/train.jl:88)");
-    ARG_CHECK(num_epochs >= 0 && world >= 1, "ppo_train!: bad epochs/world");
+    ARG_CHECK(num_epochs >= 0 && world >= 1 && rank >= 0 && rank < world, "ppo_train!: bad epochs/rank/world");
     ARG_CHECK(world == 1 || allreduce, "ppo_train!: world > 1 needs an all-reduce hook");
     ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "ppo_train!: shape mismatch");
+    ARG_CHECK(batch_size >= 1, "1 <= batch_size <= num_data (src/train.jl:88)");
     if (adv_mode != PPO_ADV_RETURNS && adv_mode != PPO_ADV_RETURNS_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
+    // Data-parallel shards may differ in length (remainder envs, episode-mode rollouts): every rank learns every
+    // rank's dataset length once per call -- an all-gather spelled as the hook's sum all-reduce over a one-hot
+    // [2*world] vector (length split into two exactly representable floats) -- and derives from them the SAME
+    // number of optimiser steps and the exact global minibatch size of each step.  A rank whose shard is exhausted
+    // contributes a zero gradient to the remaining steps, so all ranks issue the same collectives.
+    std::vector<int64_t> lens((size_t)world, len);
+    if (world > 1) {
+        DevBuf<float> xch;
+        PPO_TRY(xch.alloc((size_t)2 * world));
+        std::vector<float> hx((size_t)2 * world, 0.0f);
+        hx[2 * (size_t)rank] = (float)(len >> 12); hx[2 * (size_t)rank + 1] = (float)(len & 4095);
+        PPO_TRY(h2d(xch.p, hx.data(), hx.size()));
+        if (allreduce(allreduce_ctx, xch.p, 2 * (int64_t)world) != 0) { ppo_set_error("all-reduce hook failed (shard-length exchange)"); return PPO_ERR_ARG; }
+        PPO_TRY(d2h(hx.data(), xch.p, hx.size()));
+        for (int32_t r = 0; r < world; ++r) lens[(size_t)r] = ((int64_t)hx[2 * (size_t)r] << 12) + (int64_t)hx[2 * (size_t)r + 1];
+        ARG_CHECK(lens[(size_t)rank] == len, "ppo_train!: shard-length exchange is inconsistent (two ranks with the same rank id?)");
+    }
+    int64_t nb = 0, min_len = len;
+    for (int64_t l : lens) { nb = std::max(nb, (l + batch_size - 1) / batch_size); min_len = std::min(min_len, l); }
+    ARG_CHECK(batch_size <= min_len, "1 <= batch_size <= num_data (src/train.jl:88) on every data-parallel shard");
     PPO_TRY(train_reserve(pol, batch_size * (ro->H / 32)));
-    const int64_t nb = (len + batch_size - 1) / batch_size;
     DevBuf<int32_t> order; DevBuf<int64_t> permd; DevBuf<float> hist;
     PPO_TRY(order.alloc(len));
     if (perm) PPO_TRY(permd.alloc(len));
     PPO_TRY(hist.alloc((size_t)nb * 2));
     std::vector<float> hh((size_t)nb * 2);
-    static uint32_t epoch_counter = 0;
     for (int32_t ep = 0; ep < num_epochs; ++ep) {
         if (perm) {                                                    // randperm(num_data)  src/train.jl:93
             PPO_TRY(h2d(permd.p, perm + (size_t)ep * len, (size_t)len));
@@ -760,19 +782,25 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
                                permd.p, len, order.p, pol->err.p);
             HIP_TRY(hipGetLastError());
         } else {
-            PPO_TRY(launch_feistel_index(ro->index.p, len, seed, epoch_counter, order.p));
+            // keyed by (seed, epochs this optimiser has trained): no process-global state, so the same seed with a
+            // fresh optimiser reproduces the run and a restored optimiser (ppo_adam_set_epoch_count) resumes it
+            PPO_TRY(launch_feistel_index(ro->index.p, len, seed, (uint32_t)opt->epochs_done, order.p));
         }
-        epoch_counter++;
-        int64_t b = 0;
-        for (int64_t start = 0; start < len; start += batch_size, ++b) {           // :95-96 (last batch may be short)
-            const int64_t B = (start + batch_size <= len) ? batch_size : (len - start);
-            PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, B * world, epsilon, entropy_weight, adv_mode));
+        for (int64_t b = 0; b < nb; ++b) {                                          // :95-96 (last batch may be short)
+            const int64_t start = b * batch_size;
+            const int64_t B = std::max<int64_t>(0, std::min(batch_size, len - start));
+            int64_t Bg = 0;
+            for (int64_t l : lens) Bg += std::max<int64_t>(0, std::min(batch_size, l - start));
+            if (B > 0) PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, Bg, epsilon, entropy_weight, adv_mode));
+            else HIP_TRY(hipMemsetAsync(pol->grad.p, 0, (size_t)(pol->np + 2) * sizeof(float), g_stream));   // shard exhausted
             if (allreduce) {                     // every rank of a data-parallel run; a world of 1 may pass it too
+                ProfScope ps("allreduce");
                 const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
                 if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }
             }
             PPO_TRY(launch_adam(opt, hist.p + 2 * b));                              // Flux.update!  :81 (+ loss history)
         }
+        opt->epochs_done += 1;
         PPO_TRY(d2h(hh.data(), hist.p, (size_t)nb * 2));
         double sp = 0.0, se = 0.0;
         for (int64_t i = 0; i < nb; ++i) { sp += hh[2 * i]; se += hh[2 * i + 1]; }

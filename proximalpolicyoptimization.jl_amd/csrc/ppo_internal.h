@@ -104,6 +104,7 @@ struct ppo_adam_s {
     ppo_policy_s* pol;
     double eta, beta1, beta2, eps;
     double beta_pow[2];
+    int64_t epochs_done = 0;           // epochs trained through ppo_train: keys the minibatch permutation with the seed
     DevBuf<float> m, v;
 };
 

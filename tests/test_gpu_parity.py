@@ -709,12 +709,27 @@ def test_ppo_iterate_disk_method(P, tmp_path):
     env = P.HipVecEnv(num_envs=4, Q=8, max_actions=6, seed=1)
     pol = P.HipPolicy(72, 128, 2, 4, seed=0)
     opt = P.Optimiser(P.Adam(1e-4))
-    calls = []
+
+    class Evaluator:                                   # the reference's evaluator objects are callable structs
+        def __init__(self):
+            self.calls, self.saved = 0, None
+
+        def __call__(self, policy, env_, optimizer):
+            self.calls += 1
+
+    # save_loss is a plugin with no method anywhere in the reference: an evaluator type without one throws (:196,247)
+    with pytest.raises(P.PPOError, match="Function save_loss needs to be overloaded"):
+        P.ppo_iterate_(pol, env, opt, 8, 8, 1, Evaluator(), 1, 1.0, 0.05, 0.01, verbose=False)
+
+    @P.save_loss.register(Evaluator)
+    def _(ev, loss):
+        ev.saved = {k: list(v) for k, v in loss.items()}
+
+    ev = Evaluator()
     path = str(tmp_path / "iter_store")
-    loss = P.ppo_iterate_(pol, env, opt, 8, 8, 2, lambda p, e, o: calls.append(1), 1, 1.0, 0.05, 0.01, path,
-                          verbose=False)
-    assert len(calls) == 2 and len(loss["ppo"]) == 2 and not os.path.exists(path)
-    loss2 = P.ppo_iterate_(pol, env, opt, 8, 8, 1, lambda p, e, o: None, 2, 1.0, 0.05, 0.01, verbose=False)
+    loss = P.ppo_iterate_(pol, env, opt, 8, 8, 2, ev, 1, 1.0, 0.05, 0.01, path, verbose=False)
+    assert ev.calls == 2 and len(loss["ppo"]) == 2 and not os.path.exists(path) and ev.saved == loss
+    loss2 = P.ppo_iterate_(pol, env, opt, 8, 8, 1, Evaluator(), 2, 1.0, 0.05, 0.01, verbose=False)
     assert len(loss2["entropy"]) == 2 and loss2["lr"] == [1e-4, 1e-4]
 
 

@@ -122,3 +122,36 @@ def test_gloo_world2_gradient_allreduce(orc, tmp_path):
     g, lp, le = orc.step_batch_grad_f64(params, 72, 128, states, active, actions, p_old, adv, 0.05, 0.01)
     want = np.concatenate([g, [lp, le]])
     assert np.allclose(got, want, rtol=1e-10, atol=1e-12)
+
+
+def _run_bench(extra_env, *argv, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher environment must start two rank processes (the driver calls it
+    exactly like that).  Dry run over gloo: rank launch + rendezvous + the one JSON line, no GPU."""
+    r, out = _run_bench({"PPO_BENCH_DRYRUN": "1", "PPO_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out is not None and out["n_gpus"] == 2 and out["dry_run"] is True
+    assert sum(1 for ln in r.stdout.splitlines() if ln.startswith("{")) == 1, "exactly one JSON line"
+
+
+def test_bench_multi_gpu_never_reports_a_single_rank_silently():
+    """Without a GPU the rank processes fail: the launcher must exit non-zero and print no figure (round 1 printed a
+    1-GPU number under --gpus N)."""
+    if __import__("ppo_amd").device_count() > 0:
+        pytest.skip("a GPU is present")
+    r, out = _run_bench({"PPO_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--envs", "64",
+                        "--no-cpu-baseline")
+    assert r.returncode != 0 and out is None
