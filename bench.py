@@ -456,7 +456,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if use_dist:
-        PPO._lib.lib().ppo_rccl_finalize()         # no-op unless the in-library communicator was created
+        PPO.rccl_finalize()                        # no-op unless the in-library communicator was created
         dist.destroy_process_group()
     return 0
 

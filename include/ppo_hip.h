@@ -161,10 +161,12 @@ int32_t ppo_rollouts_dims(ppo_rollouts_t ro, int64_t* T, int64_t* N);
  * probabilities (tests only). */
 int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t T,
                              double discount, int32_t discount_is_f32, int32_t record_probs);
-/* num_episodes form: every env plays `episodes_per_env` complete episodes (reference semantics:
- * only whole episodes enter the buffer); dataset length = number of valid transitions */
+/* num_episodes form (the reference's own signature): EXACTLY num_episodes whole episodes enter the buffer
+ * (src/rollout_buffer.jl:73-77).  The N resident envs play them in parallel, episode e on env e mod N (env n plays
+ * ceil((num_episodes - n) / N) episodes, reset! before each; envs beyond num_episodes stay idle).  Dataset order =
+ * env-major concatenation of the whole episodes; length = number of valid transitions. */
 int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
-                                      int64_t episodes_per_env, double discount,
+                                      int64_t num_episodes, double discount,
                                       int32_t discount_is_f32);
 /* column getters, time-major [T,N] (dataset getindex, src/rollout_buffer.jl:103-133) */
 int32_t ppo_rollouts_get_states(ppo_rollouts_t ro, int8_t* states, uint32_t* active);
@@ -247,7 +249,7 @@ int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir);
 
 /* average_returns(policy, env, num_trajectories) -> (mean, sample std [n-1]) of the UNdiscounted episode return
  *                                                          src/evaluate.jl:1-25
- * every resident env plays ceil(num_trajectories / N) whole episodes (reset! before each, stochastic policy);
+ * exactly num_trajectories whole episodes, trajectory e on resident env e mod N (reset! before each, stochastic policy);
  * `scratch` is a rollout buffer created for this env (its contents are overwritten). */
 int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
                             double* mean, double* std);

@@ -44,9 +44,9 @@ def philox4x32_10(ctr, key):
     return np.array(c, np.uint32)
 
 
-def index_to_action(index, actions_per_edge=4):
-    """test/quad_game_utilities.jl:95-105 (1-based)."""
-    apq = 4 * actions_per_edge
+def index_to_action(index, actions_per_edge=4, edges=4):
+    """test/quad_game_utilities.jl:95-105 (1-based); edges=3 is the tutorial notebook's triangle variant."""
+    apq = edges * actions_per_edge
     quad = (index - 1) // apq + 1
     qa = (index - 1) % apq
     return quad, qa // actions_per_edge + 1, qa % actions_per_edge + 1

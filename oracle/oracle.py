@@ -74,6 +74,7 @@ def lib():
         L.orc_gae_tn.argtypes = [c_f32p, c_u8p, c_f32p, C.c_int64, C.c_int64, C.c_double, C.c_double, c_f32p, c_f32p]
         L.orc_philox4x32_10.argtypes = [c_u32p, c_u32p, c_u32p]
         L.orc_index_to_action.argtypes = [C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p]
+        L.orc_index_to_action_edges.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p]
         L.orc_action_mask.argtypes = [c_u8p, C.c_int32, C.c_int32, c_f32p]
         L.orc_mlp_logits_ref.argtypes = [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f32p]
         L.orc_mlp_logits_f64.argtypes = [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f64p]
@@ -141,9 +142,10 @@ def feistel_perm(n, seed, epoch):
     return np.array([L.orc_feistel_perm(i, n, seed, epoch) for i in range(n)], np.int64)
 
 
-def index_to_action(index1, actions_per_edge=4):
+def index_to_action(index1, actions_per_edge=4, edges=4):
+    """edges=4: the quad game (test/quad_game_utilities.jl:95-105); edges=3: the notebook's triangle variant."""
     q, e, t = C.c_int32(), C.c_int32(), C.c_int32()
-    lib().orc_index_to_action(index1, actions_per_edge, C.byref(q), C.byref(e), C.byref(t))
+    lib().orc_index_to_action_edges(index1, edges, actions_per_edge, C.byref(q), C.byref(e), C.byref(t))
     return q.value, e.value, t.value
 
 

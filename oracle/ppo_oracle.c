@@ -288,12 +288,19 @@ void orc_env_step_one(orc_env* e, int64_t n, int32_t a) {
     e->done[n] = (uint8_t)((new_total == opt) || (e->steps[n] >= e->max_actions));
 }
 
+/* index_to_action for elements with `edges` edges (4: the quad game, test/quad_game_utilities.jl:95-105;
+ * 3: the triangle variant of the tutorial notebook, whose printed answers pin it: learn_flip.ipynb:19669-19699) */
+void orc_index_to_action_edges(int32_t index1, int32_t edges, int32_t actions_per_edge, int32_t* elem, int32_t* edge,
+                               int32_t* type) {
+    int ape = edges * actions_per_edge;            /* actions per element */
+    *elem = (index1 - 1) / ape + 1;
+    int ea = (index1 - 1) % ape;
+    *edge = ea / actions_per_edge + 1;
+    *type = ea % actions_per_edge + 1;
+}
+
 void orc_index_to_action(int32_t index1, int32_t actions_per_edge, int32_t* quad, int32_t* edge, int32_t* type) {
-    int apq = 4 * actions_per_edge;
-    *quad = (index1 - 1) / apq + 1;
-    int qa = (index1 - 1) % apq;
-    *edge = qa / actions_per_edge + 1;
-    *type = qa % actions_per_edge + 1;
+    orc_index_to_action_edges(index1, 4, actions_per_edge, quad, edge, type);
 }
 
 void orc_action_mask(const uint8_t* active_quad, int32_t Q, int32_t actions_per_edge, float* mask_out) {

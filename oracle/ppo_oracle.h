@@ -76,6 +76,8 @@ void orc_env_observe_one(const orc_env* e, int64_t n, int8_t* obs /*[H][F]*/);
 int32_t orc_env_template(int32_t Q, int32_t h, int32_t t); /* vertex id or -1 */
 /* (quad,edge,type) 1-based decode of a 1-based index: test/quad_game_utilities.jl:95-105 */
 void orc_index_to_action(int32_t index1, int32_t actions_per_edge, int32_t* quad, int32_t* edge, int32_t* type);
+void orc_index_to_action_edges(int32_t index1, int32_t edges, int32_t actions_per_edge, int32_t* elem, int32_t* edge,
+                               int32_t* type);
 /* action mask over A entries: 0 or -Inf (test/quad_game_utilities.jl:39-44) */
 void orc_action_mask(const uint8_t* active_quad, int32_t Q, int32_t actions_per_edge, float* mask_out);
 

@@ -599,8 +599,9 @@ def _discount_args(discount):
 
 def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     """PPO.collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79,
-    src/rollouts_to_disk.jl:134-147).  The N resident envs each play ceil(num_episodes / N) whole episodes
-    (reset! before each).  A DiskRollouts target additionally gets the reference's CSV + BSON layout."""
+    src/rollouts_to_disk.jl:134-147).  Exactly num_episodes whole episodes enter the buffer: the N resident envs play
+    them in parallel, episode e on env e mod N (reset! before each).  A DiskRollouts target additionally gets the
+    reference's CSV + BSON layout."""
     if not isinstance(env, HipVecEnv):
         # generic method: the reference's own per-step control flow over the user's plugin methods (an env without a
         # `state` method raises "Function state needs to be overloaded" from inside it, like the reference)
@@ -624,7 +625,7 @@ def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     per_env = -(-int(num_episodes) // env.N)
     h = rollouts._ensure(env, per_env * env.max_actions)
     g, f32 = _discount_args(discount)
-    call("ppo_collect_rollouts_episodes", h, env._h, policy._h, per_env, g, f32)
+    call("ppo_collect_rollouts_episodes", h, env._h, policy._h, int(num_episodes), g, f32)
 
 
 def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=4):
@@ -968,6 +969,14 @@ def _native_rccl_hook_impl(rank, world):
     sys.stderr.write("rank %d: native RCCL hook not adopted (%s); every rank uses the torch.distributed hook\n"
                      % (rank, why or "another rank failed"))
     return None
+
+
+def rccl_finalize():
+    """Destroy the library's communicator (if any) and forget the cached native hook, so a later process group can
+    build a new one."""
+    global _NATIVE_RCCL_HOOK
+    _NATIVE_RCCL_HOOK = False
+    call("ppo_rccl_finalize")
 
 
 def rccl_comm_info():

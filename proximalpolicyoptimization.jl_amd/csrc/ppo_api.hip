@@ -521,21 +521,23 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     return ppo_env_check_errors(env, nullptr);
 }
 
-__global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+// episode e of the call is played by env e mod N: env n plays episodes n, n + N, n + 2N, ... below num_episodes
+__global__ void k_episode_quota(int32_t* left, int64_t N, int64_t num_episodes) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) left[n] = n < num_episodes ? (int32_t)((num_episodes - n + N - 1) / N) : 0;
 }
 
-int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t episodes_per_env,
+int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol, int64_t num_episodes,
                                       double discount, int32_t discount_is_f32) {
     PPO_TRY(check_shapes(ro, env, pol));
-    ARG_CHECK(episodes_per_env >= 1, "collect_rollouts!: num_episodes must be >= 1");
+    ARG_CHECK(num_episodes >= 1, "collect_rollouts!: num_episodes must be >= 1");
     const int64_t N = env->N;
+    const int64_t episodes_per_env = (num_episodes + N - 1) / N;       // the busiest env (env 0)
     const int64_t Tmax = episodes_per_env * env->max_actions;
     PPO_TRY(rollouts_reserve(ro, Tmax));
     const size_t srow = (size_t)N * env->H * env->F;
-    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, g_stream, env->episodes_left.p, N,
-                       (int32_t)episodes_per_env);
+    hipLaunchKernelGGL(k_episode_quota, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, g_stream, env->episodes_left.p, N,
+                       num_episodes);
     PPO_TRY(launch_env_reset(env, 0));                                  // reset!(env) before the first episode
     std::vector<int32_t> left((size_t)N);
     int64_t T = 0;
@@ -576,7 +578,7 @@ int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scra
     ARG_CHECK(pol && env && scratch && mean && std && num_trajectories >= 1, "average_returns: bad argument");
     const int64_t N = env->N;
     const int64_t per_env = (num_trajectories + N - 1) / N;
-    PPO_TRY(ppo_collect_rollouts_episodes(scratch, env, pol, per_env, 1.0, 0));
+    PPO_TRY(ppo_collect_rollouts_episodes(scratch, env, pol, num_trajectories, 1.0, 0));   // exactly num_trajectories (:19-22)
     const int64_t T = scratch->T;
     std::vector<float> r((size_t)T * N);
     std::vector<uint8_t> dn((size_t)T * N), va((size_t)T * N);

@@ -187,9 +187,21 @@ def test_policy_forward(P, orc, golden_dir, F, HID, fixture):
         mask = orc.action_mask([(int(active[b]) >> q) & 1 for q in range(8)])
         assert np.all(probs[b][np.isneginf(mask)] == 0.0)
         assert abs(float(probs[b].sum()) - 1.0) < 1e-5
-        if not fixture:        # random-init weights: compare with the natural-order fp32 and fp64 restatements
+        if not fixture:        # random-init weights: compare with the natural-order fp32 restatement
             ref = orc.action_probabilities(params, F, HID, states[b], active[b], "ref")
             assert np.allclose(probs[b], ref, rtol=2e-5, atol=1e-8)
+        # INDEPENDENT check, every weight set (the reference-trained ones have logits of O(10-100), so probabilities are
+        # compared in logit space): float64 restatement in natural order -> masked log-softmax.  Tolerance: fp32
+        # accumulation over 72..256-term dot products, |d log p| <= 1e-4 * max(1, max|logit|).
+        l64 = orc.mlp_logits(params, F, HID, states[b], "f64")
+        on = ~np.isneginf(mask)
+        lse = np.log(np.exp(l64[on] - l64[on].max()).sum()) + l64[on].max()
+        live = on & (probs[b] > 1e-30)
+        assert live.sum() >= 1
+        tol = 1e-4 * max(1.0, float(np.abs(l64[on]).max()))
+        assert np.abs(np.log(probs[b][live].astype(np.float64)) - (l64[live] - lse)).max() <= tol
+        dead = on & ~live                       # underflowed on the device: the f64 value must be negligible too
+        assert np.all(l64[dead] - lse < -60.0)
     single = P.action_probabilities(pol, P.StateData(states[0], active[0]))
     assert np.array_equal(single, probs[0])
 
@@ -382,6 +394,33 @@ def test_gradient_vs_f64_oracle(P, orc, HID, B):
     # run-to-run bitwise reproducibility (fixed-order slab reduction, no float atomics)
     P.forward_backward(pol, ds, sel, 0.05, 0.01)
     assert np.array_equal(g, pol.grad())
+
+
+@pytest.mark.parametrize("fixture", ["poly-30-policy", "catmull-clark-policy"])
+def test_gradient_with_reference_trained_weights(P, orc, golden_dir, fixture):
+    """Zygote's gradient (src/train.jl:65-79) restated in float64, on the weights the REFERENCE trained
+    (test/output/*.bson decoded into tests/golden/*.npz): rollout with those weights on the engine, then loss and
+    gradient of a minibatch against orc_step_batch_grad_f64 -- same tolerance as for random-init weights."""
+    params = np.load(os.path.join(golden_dir, fixture + ".npz"))["params"]
+    env = P.HipVecEnv(num_envs=32, Q=8, max_actions=12, seed=17)
+    pol = P.HipPolicy(72, 128, 2, 4, seed=0)
+    pol.params = params
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, 12, 1.0)
+    ds = P.construct_dataset(ro)
+    sel = np.random.default_rng(2).permutation(len(ds))[:200] + 1
+    for eps, ew in ((0.05, 0.01), (0.2, 0.0)):
+        lp, le = P.forward_backward(pol, ds, sel, eps, ew)
+        g = pol.grad()
+        g64, olp, ole = _oracle_grad(orc, params, 128, ro, sel - 1, eps, ew)
+        scale = np.abs(g64).max()
+        assert scale > 0 and np.abs(g - g64).max() <= 2e-5 * scale + 1e-9
+        assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    # the rollout itself (sampled actions, probabilities) is bit-exact against the device-order oracle with these weights
+    oenv = orc.Env(Q=8, max_actions=12, N=32, seed=17)
+    oenv.reset()
+    ref = orc.collect_rollouts_tn(oenv, params, 128, 12, mode_dev=True)
+    assert np.array_equal(ro.selected_actions - 1, ref["actions"]) and np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
 
 
 def test_gradient_clipped_branch(P, orc):
@@ -584,8 +623,9 @@ def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode):
     assert np.isfinite(ph[0]) and np.isfinite(eh[0])
 
 
-def test_config4_size_properties(P, orc):
-    """BASELINE config 4 size: 8192 envs, Q=32 (A=512), masked actions, variable-length episodes."""
+def test_config4_size_properties(P, orc, rollout_mode):
+    """BASELINE config 4 size: 8192 envs, Q=32 (A=512), masked actions, variable-length episodes; both rollout
+    executions (per-step launches and the one-launch persistent rollout)."""
     N, T = 8192, 16
     env = P.HipVecEnv(num_envs=N, Q=32, max_actions=12, seed=4)
     pol = P.HipPolicy(72, 128, 2, 4, seed=0)
@@ -605,11 +645,14 @@ def test_config4_size_properties(P, orc):
 
 
 # ---------------------------------------------------------------- data-parallel plumbing on one GPU
-def test_allreduce_hook_single_rank_rccl(P, orc):
-    """One-rank RCCL group: the gradient buffer is aliased as a torch tensor and all-reduced on the engine's
-    stream every optimiser step.  With one rank the sum is the identity, so training must be bit-identical
-    to the hook-free run (validates aliasing, stream ordering and the C callback)."""
+@pytest.mark.parametrize("kind", ["torch.distributed/nccl", "native-rccl"])
+def test_allreduce_hook_single_rank_rccl(P, orc, kind, monkeypatch):
+    """One-rank RCCL group, both hook kinds DataParallel.make_hook can hand to ppo_train: the library's own RCCL
+    all-reduce (default) and a torch.distributed all-reduce on a tensor aliasing the gradient buffer (PPO_NATIVE_RCCL=0).
+    With one rank the sum is the identity, so training must be bit-identical to the hook-free run (validates
+    aliasing, stream ordering, the C callback and the seed-only minibatch order)."""
     import socket
+    monkeypatch.setenv("PPO_NATIVE_RCCL", "1" if kind == "native-rccl" else "0")
     import torch
     import torch.distributed as dist
     s = socket.socket()
@@ -627,26 +670,48 @@ def test_allreduce_hook_single_rank_rccl(P, orc):
             ds = P.construct_dataset(ro)
             opt = P.Optimiser(P.Adam(1e-3))
             dp = P.DataParallel(0, 1, force_hook=hook)
-            perm = np.stack([np.random.default_rng(e).permutation(len(ds)) + 1 for e in range(2)])   # same order twice
-            ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 64, 2, 0.01, perm=perm, parallel=dp, verbose=False)
+            ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 64, 2, 0.01, seed=11, parallel=dp, verbose=False)
             torch.cuda.synchronize()
             res.append((pol.params.copy(), ph, eh))
+            assert dp.hook_kind == (kind if hook else None)
         assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] and res[0][2] == res[1][2]
     finally:
+        P.rccl_finalize()
         dist.destroy_process_group()
 
 
+def test_collect_rollouts_exact_num_episodes(P):
+    """src/rollout_buffer.jl:73-77: exactly num_episodes episodes enter the buffer, also when the env batch does not
+    divide num_episodes (episode e runs on env e mod N; envs beyond num_episodes stay idle)."""
+    for N, num_episodes in ((6, 8), (6, 3), (4, 9), (5, 5)):
+        env = P.HipVecEnv(num_envs=N, Q=8, max_actions=6, seed=21)
+        pol = P.HipPolicy(72, 128, 2, 4, seed=4)
+        ro = P.BufferRollouts()
+        P.collect_rollouts_(ro, env, pol, num_episodes, 1.0)
+        valid, term = ro.valid, ro.terminal
+        assert int((valid & term).sum()) == num_episodes
+        per_env = (valid & term).sum(axis=0)
+        assert list(per_env) == [len(range(n, num_episodes, N)) for n in range(N)]
+        idx = ro.index()
+        assert len(idx) == len(ro) == int(valid.sum()) and term.reshape(-1)[idx][-1]
+        # whole episodes only: in every env column the valid flags form a prefix that ends on a terminal
+        for n in range(N):
+            k = int(valid[:, n].sum())
+            assert valid[:k, n].all() and not valid[k:, n].any() and (k == 0 or term[k - 1, n])
+
+
 def test_average_returns_evaluator(P, orc):
-    """src/evaluate.jl:18-25 -- mean / sample-std of undiscounted episode returns, checked against an oracle replay."""
-    N, per_env = 6, 2
+    """src/evaluate.jl:18-25 -- mean / sample-std of undiscounted episode returns, checked against an oracle replay.
+    11 trajectories on 6 envs: exactly 11 are played (envs 0..4 two each, env 5 one)."""
+    N, num_traj = 6, 11
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=7, seed=13)
     pol = P.HipPolicy(72, 128, 2, 4, seed=3)
-    mean, std = P.average_returns(pol, env, N * per_env)
+    mean, std = P.average_returns(pol, env, num_traj)
     oenv = orc.Env(Q=8, max_actions=7, N=N, seed=13)
     oenv.episode[:] = 1                                  # create() consumed episode 0 on the device side
     rets = []
     for n in range(N):
-        for ep in range(per_env):
+        for ep in range(len(range(n, num_traj, N))):
             oenv.reset_one(n)
             acc = 0.0
             while not oenv.done[n]:

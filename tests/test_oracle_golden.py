@@ -46,13 +46,10 @@ def test_returns_test_env(orc, golden_dir):
 
 def test_index_to_action(orc, golden_dir):
     k = _known(golden_dir)["index_to_action_triangle"]
-    for idx, exp in k["cases"]:      # notebook known answers (3 edges x 2 types)
-        quad, edge, typ = np_oracle.index_to_action(idx, k["actions_per_edge"])
-        # triangle variant has 3 edges: same formula with actions_per_quad = 3*2
-        apq = k["edges"] * k["actions_per_edge"]
-        q = (idx - 1) // apq + 1
-        qa = (idx - 1) % apq
-        assert [q, qa // k["actions_per_edge"] + 1, qa % k["actions_per_edge"] + 1] == exp
+    for idx, exp in k["cases"]:      # notebook known answers (3 edges x 2 types): (1,3,1) for 5 and (2,2,1) for 9
+        assert list(orc.index_to_action(idx, k["actions_per_edge"], edges=k["edges"])) == exp
+        assert list(np_oracle.index_to_action(idx, k["actions_per_edge"], edges=k["edges"])) == exp
+    assert list(orc.index_to_action(9, 2, edges=4)) == [2, 1, 1]      # the quad formula on the same index differs
     # quad variant (test/quad_game_utilities.jl:95-105): exhaustive agreement C vs numpy
     for idx in range(1, 16 * 8 + 1):
         assert orc.index_to_action(idx) == np_oracle.index_to_action(idx)
