@@ -376,6 +376,12 @@ def main():
         gbs = 9.0 * 128 * 262144 / (ms * 1e-3) / 1e9
         kernels["k_returns_tn@262144x128"] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
                                               "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
+        # GAE(gamma, lambda) scan at the same size: 17 B/transition (r f32 + done u8 + V f32 in, adv f32 + lambda-return f32 out)
+        for cols, it in ((65536, 20), (262144, 10)):
+            ms = PPO.profile_gae(128, cols, 0.99, 0.95, it)
+            gbs = 17.0 * 128 * cols / (ms * 1e-3) / 1e9
+            kernels["k_gae_tn@%dx128" % cols] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
+                                                  "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
         k = kernels.get("k_policy_bwd")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run

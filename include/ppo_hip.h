@@ -46,6 +46,8 @@ typedef struct ppo_rollouts_s* ppo_rollouts_t;
  * implementation exists in the reference, old scripts use raw returns) */
 #define PPO_ADV_RETURNS 0            /* advantage = returns (what the reference's old scripts do)            */
 #define PPO_ADV_RETURNS_NORMALISED 1 /* (R - mean) / (std + 1e-8) over the minibatch (population std, fp64 stats) */
+#define PPO_ADV_GAE 2                /* the GAE(gamma, lambda) column of ppo_rollouts_compute_gae (host-supplied state values) */
+#define PPO_ADV_GAE_NORMALISED 3     /* the same, normalised over the minibatch like mode 1 */
 
 /* ---------------------------------------------------------------- library / device */
 int32_t ppo_version(void);
@@ -59,6 +61,13 @@ int32_t ppo_device_count(int32_t* out);
  * steps with the env state in LDS), -1 (default) = automatic: one launch for Q = 8 envs, per-step launches otherwise.
  * Same results bit for bit; per-step launches are always used while a disk sink is attached. */
 int32_t ppo_set_rollout_persistent(int32_t mode);
+/* state storage of engine-collected rollouts (R4, src/rollout_buffer.jl:1-22: the reference boxes every state):
+ * 0 = expanded observation rows [H][F] int8 per transition (2304 B for Q = 8), 1 = compact: the env snapshot the rows
+ * are derived from (score[V] + degree[V] int8 = 64 B for Q = 8, plus the active-quad word) -- the train forward
+ * re-derives the rows exactly as state(env) does, the getters expand on demand; -1 (default) = automatic: compact when
+ * the expanded rollout would exceed 4 GiB (PPO_COMPACT_AUTO_BYTES) or while a disk sink is attached (the streamed
+ * record shrinks 28x).  Same results bit for bit.  Host-supplied rollouts (ppo_rollouts_set) are always expanded. */
+int32_t ppo_set_rollout_compact(int32_t mode);
 
 /* ---------------------------------------------------------------- standalone ops (parity entry points) */
 /* compute_returns(rewards, terminal, discount)            src/collect_rollouts.jl:26-42
@@ -179,6 +188,14 @@ int32_t ppo_rollouts_get_valid(ppo_rollouts_t ro, uint8_t* valid);
 int32_t ppo_rollouts_get_full_probs(ppo_rollouts_t ro, float* probs);   /* [T,N,A], record_probs only */
 /* dataset order: flat index list of the valid transitions (t*N+n), length = ppo_rollouts_len */
 int32_t ppo_rollouts_get_index(ppo_rollouts_t ro, int64_t* idx);
+/* batch_advantage as GAE(gamma, lambda) (north_star "GAE advantage reverse scan"; the reference declares the plugin at
+ * src/ProximalPolicyOptimization.jl:29 and implements nothing).  values: [T+1][N] state values from the caller's critic
+ * (row T = bootstrap value behind the last step; the reference has no value head).  Runs the LDS-tiled fp64 scan over
+ * the buffer's raw rewards / terminal flags and keeps the advantage column on the device for adv_mode PPO_ADV_GAE*;
+ * optional host copies of the advantages and of the lambda-returns adv + V.  lambda = 1 and V = 0 reproduce
+ * compute_returns (src/collect_rollouts.jl:26-42) bit for bit. */
+int32_t ppo_rollouts_compute_gae(ppo_rollouts_t ro, const float* values, double gamma, double lambda,
+                                 float* adv_out_or_null, float* lambda_returns_out_or_null);
 /* load columns from host (tests / generic host-side envs) */
 int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, const uint32_t* active,
                          const int32_t* actions0, const float* p_sel, const float* returns,
@@ -259,6 +276,7 @@ int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scra
 /* measurement helper: run the return scan `iters` times on device-resident synthetic [T,N] columns (no host
  * copies in the timed region) and report the average kernel time (HIP events).  K6 roofline leg of bench.py. */
 int32_t ppo_profile_returns(int64_t T, int64_t N, double discount, int32_t iters, double* avg_ms);
+int32_t ppo_profile_gae(int64_t T, int64_t N, double gamma, double lambda, int32_t iters, double* avg_ms);
 int32_t ppo_profile_enable(int32_t on);
 int32_t ppo_profile_get(const char* kernel_name, double* total_ms, int64_t* launches);
 

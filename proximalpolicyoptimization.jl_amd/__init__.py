@@ -45,7 +45,7 @@ __all__ = [
     "PPOError", "HipVecEnv", "HipPolicy", "Adam", "Optimiser", "StateData", "BufferRollouts", "BufferDataset",
     "state", "reward", "is_terminal", "reset_", "step_", "action_probabilities", "batch_action_probabilities",
     "batch_state", "number_of_actions_per_state", "batch_advantage", "save_loss", "compute_returns",
-    "compute_returns_tn", "gae_tn", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
+    "compute_returns_tn", "gae_tn", "compute_gae_", "profile_gae", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
     "simplified_ppo_clip", "get_linear_action_index", "ppo_loss_with_entropy", "categorical_sample", "step_batch_",
     "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
     "device_count", "average_returns", "DiskRollouts", "DiskDataset", "update_", "write_returns_to_disk",
@@ -97,6 +97,13 @@ def set_rollout_persistent(on=None):
     call("ppo_set_rollout_persistent", -1 if on is None else int(bool(on)))
 
 
+def set_rollout_compact(on=None):
+    """State storage of engine-collected rollouts: True = compact env snapshots (64 B per transition for Q = 8; the train
+    forward re-derives the observation rows), False = expanded observations (2304 B), None = automatic (compact above
+    4 GiB of expanded states or while streaming to disk).  Bit-identical results either way."""
+    call("ppo_set_rollout_compact", -1 if on is None else int(bool(on)))
+
+
 def synchronize():
     call("ppo_device_synchronize")
 
@@ -109,6 +116,13 @@ def profile_returns(T, N, discount=1.0, iters=20):
     """Average device time (ms) of the return scan on resident [T,N] columns (K6 roofline measurement)."""
     ms = C.c_double(0)
     call("ppo_profile_returns", int(T), int(N), float(discount), int(iters), C.byref(ms))
+    return ms.value
+
+
+def profile_gae(T, N, gamma=0.99, lam=0.95, iters=20):
+    """Average device time (ms) of the GAE scan on resident [T,N] columns (17 B/transition roofline measurement)."""
+    ms = C.c_double(0)
+    call("ppo_profile_gae", int(T), int(N), float(gamma), float(lam), int(iters), C.byref(ms))
     return ms.value
 
 
@@ -634,7 +648,7 @@ def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_p
     while the next step runs (ppo_rollouts_attach_disk)."""
     if isinstance(rollouts, DiskRollouts):
         dev = BufferRollouts()
-        h = dev._ensure(env, int(num_steps))
+        h = dev._ensure(env, 0)          # capacity comes with the collection (its storage form depends on the sink)
         # the constructor already wiped the directory; attach recreates it (same semantics) for the shard
         call("ppo_rollouts_attach_disk", h, rollouts.state_data_directory.encode(), int(pinned_slots))
         g, f32 = _discount_args(discount)
@@ -648,6 +662,19 @@ def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_p
     h = rollouts._ensure(env, int(num_steps))
     g, f32 = _discount_args(discount)
     call("ppo_collect_rollouts", h, env._h, policy._h, int(num_steps), g, f32, int(bool(record_probs)))
+
+
+def compute_gae_(rollouts, values, gamma, lam):
+    """batch_advantage as GAE(gamma, lambda): `values` [T+1, N] are the caller's state values (row T = bootstrap).  The
+    advantage column stays on the device for ppo_train_(..., advantage="gae"); returns (advantages, lambda_returns)."""
+    T, N = rollouts.dims()
+    v = np.ascontiguousarray(values, np.float32)
+    if v.shape != (T + 1, N):
+        raise PPOError(-1, "AssertionError: values must be [T+1, N] = [%d, %d]" % (T + 1, N))
+    adv, ret = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    call("ppo_rollouts_compute_gae", rollouts._h, _p(v, _lib.c_f32p), float(gamma), float(lam), _p(adv, _lib.c_f32p),
+         _p(ret, _lib.c_f32p))
+    return adv, ret
 
 
 class BufferDataset:
@@ -732,12 +759,13 @@ def load_disk_rollouts(state_data_dir, env):
 
 
 # ------------------------------------------------------------------ training
-ADVANTAGE_MODES = {"returns": 0, "returns_normalised": 1}
+ADVANTAGE_MODES = {"returns": 0, "returns_normalised": 1, "gae": 2, "gae_normalised": 3}
 
 
 def _adv_mode(advantage):
     """batch_advantage plugin (src/ProximalPolicyOptimization.jl:29; no implementation in the reference): "returns"
-    (identity, what the reference's scripts do) or "returns_normalised" ((R - mean) / (std + 1e-8) per minibatch)."""
+    (identity, what the reference's scripts do), "returns_normalised" ((R - mean) / (std + 1e-8) per minibatch), "gae"
+    (the GAE(gamma, lambda) column of compute_gae_) or "gae_normalised"."""
     if advantage not in ADVANTAGE_MODES:
         raise PPOError(-1, "AssertionError: advantage must be one of %s" % sorted(ADVANTAGE_MODES))
     return ADVANTAGE_MODES[advantage]

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ppo_env_get_terminal": [H, c_u8p],
     "ppo_env_get_internal": [H, c_i8p, c_i8p, c_i32p, c_u32p, c_u32p],
     "ppo_set_rollout_persistent": [C.c_int32],
+    "ppo_set_rollout_compact": [C.c_int32],
     "ppo_env_check_errors": [H, c_i32p],
     "ppo_env_set_strict_sampling": [H, C.c_int32],
     "ppo_policy_create": [C.c_int32, C.c_int32, C.c_int32, C.c_int32, HP],
@@ -93,6 +94,8 @@ SIGNATURES = {
     "ppo_rollouts_load_disk": [H, C.c_char_p],
     "ppo_average_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
     "ppo_profile_returns": [C.c_int64, C.c_int64, C.c_double, C.c_int32, c_f64p],
+    "ppo_profile_gae": [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p],
+    "ppo_rollouts_compute_gae": [H, c_f32p, C.c_double, C.c_double, c_f32p, c_f32p],
     "ppo_rccl_unique_id": [C.c_void_p],
     "ppo_rccl_init": [C.c_int32, C.c_int32, C.c_void_p],
     "ppo_rccl_allreduce": [C.c_void_p, C.c_void_p, C.c_int64],

@@ -162,6 +162,29 @@ int32_t ppo_profile_returns(int64_t T, int64_t N, double discount, int32_t iters
     return PPO_OK;
 }
 
+int32_t ppo_profile_gae(int64_t T, int64_t N, double gamma, double lambda, int32_t iters, double* avg_ms) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(T >= 1 && N >= 1 && iters >= 1 && avg_ms, "profile_gae: bad argument");
+    const size_t n = (size_t)T * N;
+    DevBuf<float> r, v, a, o; DevBuf<uint8_t> d;
+    PPO_TRY(r.alloc(n)); PPO_TRY(v.alloc(n + N)); PPO_TRY(a.alloc(n)); PPO_TRY(o.alloc(n)); PPO_TRY(d.alloc(n));
+    HIP_TRY(hipMemsetAsync(r.p, 0x3c, n * 4, g_stream));          // ~0.0115 everywhere
+    HIP_TRY(hipMemsetAsync(v.p, 0x3c, (n + N) * 4, g_stream));
+    HIP_TRY(hipMemsetAsync(d.p, 0, n, g_stream));
+    PPO_TRY(launch_gae_tn(r.p, d.p, v.p, a.p, o.p, T, N, gamma, lambda));   // warm-up
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, g_stream));
+    for (int i = 0; i < iters; ++i) PPO_TRY(launch_gae_tn(r.p, d.p, v.p, a.p, o.p, T, N, gamma, lambda));
+    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    return PPO_OK;
+}
+
 // ================================================================ standalone ops
 int32_t ppo_compute_returns(const float* rewards, const uint8_t* terminal, int64_t n, double discount,
                             int32_t discount_is_f32, float* out) {
@@ -270,6 +293,18 @@ int32_t ppo_env_dims(ppo_env_t env, int64_t* N, int32_t* H, int32_t* F, int32_t*
 // -1 = auto (persistent where it is the faster form: Q = 8, wavefront-parallel env update), 0 = off, 1 = on wherever covered
 static int g_rollout_persistent = [] { const char* v = std::getenv("PPO_ROLLOUT_PERSISTENT"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; }();
 int32_t ppo_set_rollout_persistent(int32_t mode) { g_rollout_persistent = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
+
+// state storage of engine-collected rollouts: -1 = automatic (compact env snapshots when the expanded observations of
+// the requested rollout would exceed PPO_COMPACT_AUTO_BYTES -- default 4 GiB -- or when a disk sink is attached: the
+// stream then carries 64 + 4 instead of 2304 + 4 state bytes per env-step for Q = 8), 0 = always expanded, 1 = always compact
+static int g_rollout_compact = [] { const char* v = std::getenv("PPO_ROLLOUT_COMPACT"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; }();
+int32_t ppo_set_rollout_compact(int32_t mode) { g_rollout_compact = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
+static bool want_compact(const ppo_rollouts_s* ro, int64_t T) {
+    if (g_rollout_compact >= 0) return g_rollout_compact == 1;
+    if (ro->sink) return true;
+    static const double limit = [] { const char* v = std::getenv("PPO_COMPACT_AUTO_BYTES"); return v ? atof(v) : 4.0 * 1024 * 1024 * 1024; }();
+    return (double)T * (double)ro->N * ro->H * ro->F > limit;
+}
 
 int32_t ppo_env_set_strict_sampling(ppo_env_t env, int32_t strict) { ARG_CHECK(env, "null env"); env->strict_sampling = strict ? 1 : 0; return PPO_OK; }
 
@@ -434,10 +469,16 @@ int32_t ppo_adam_get_epoch_count(ppo_adam_t opt, int64_t* epochs) { ARG_CHECK(op
 int32_t ppo_adam_set_epoch_count(ppo_adam_t opt, int64_t epochs) { ARG_CHECK(opt && epochs >= 0, "bad epoch count"); opt->epochs_done = epochs; return PPO_OK; }
 
 // ================================================================ rollouts
-static int32_t rollouts_reserve(ppo_rollouts_s* r, int64_t T) {
+// capacity for T steps in the requested state-storage form (the other form's buffer is released: the two differ by
+// 36x in size and a buffer switches form only when the caller changes ppo_set_rollout_compact between collections)
+int32_t rollouts_reserve(ppo_rollouts_s* r, int64_t T, bool compact) {
+    const int64_t cap = std::max(T, r->capT);
+    const size_t n = (size_t)cap * r->N;
+    if (compact) { PPO_TRY(r->cstate.alloc(n * 2 * r->V)); r->states.release(); }
+    else { PPO_TRY(r->states.alloc(n * r->H * r->F)); r->cstate.release(); }
+    r->compact = compact;
     if (T <= r->capT) return PPO_OK;
-    const size_t n = (size_t)T * r->N;
-    PPO_TRY(r->states.alloc(n * r->H * r->F)); PPO_TRY(r->active.alloc(n)); PPO_TRY(r->actions.alloc(n));
+    PPO_TRY(r->active.alloc(n)); PPO_TRY(r->actions.alloc(n));
     PPO_TRY(r->p_sel.alloc(n)); PPO_TRY(r->rewards.alloc(n)); PPO_TRY(r->returns.alloc(n)); PPO_TRY(r->done.alloc(n));
     PPO_TRY(r->valid.alloc(n)); PPO_TRY(r->index.alloc(n));
     r->capT = T;
@@ -448,8 +489,10 @@ int32_t ppo_rollouts_create(ppo_env_t env, int64_t capacity_T, ppo_rollouts_t* o
     PPO_TRY(ensure_init());
     ARG_CHECK(env && out && capacity_T >= 0, "BufferRollouts: bad argument");
     ppo_rollouts_s* r = new ppo_rollouts_s();
-    r->N = env->N; r->H = env->H; r->F = env->F; r->A = env->A; r->capT = 0; r->T = 0; r->len = 0;
-    int32_t s = rollouts_reserve(r, capacity_T);
+    r->N = env->N; r->H = env->H; r->F = env->F; r->A = env->A; r->V = env->V; r->capT = 0; r->T = 0; r->len = 0;
+    int32_t s = r->tmpl.alloc((size_t)env->H * PPO_TPL);
+    if (!s && hipMemcpyAsync(r->tmpl.p, env->tmpl.p, (size_t)env->H * PPO_TPL, hipMemcpyDeviceToDevice, g_stream) != hipSuccess) s = PPO_ERR_HIP;
+    if (!s) s = rollouts_reserve(r, capacity_T, want_compact(r, capacity_T));
     if (s) { delete r; return s; }
     *out = r;
     return PPO_OK;
@@ -465,7 +508,7 @@ __global__ void k_iota(int32_t* p, int64_t n) {
     if (i < n) p[i] = (int32_t)i;
 }
 
-static int32_t set_index_all(ppo_rollouts_s* r) {
+int32_t set_index_all(ppo_rollouts_s* r) {
     const int64_t n = r->T * r->N;
     r->len = n; r->all_valid = true;
     if (n == 0) return PPO_OK;
@@ -487,9 +530,11 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
                              int32_t discount_is_f32, int32_t record_probs) {
     PPO_TRY(check_shapes(ro, env, pol));
     ARG_CHECK(T >= 1, "collect_rollouts!: T must be >= 1");
-    PPO_TRY(rollouts_reserve(ro, T));
+    const bool compact = want_compact(ro, T);
+    PPO_TRY(rollouts_reserve(ro, T, compact));
     const int64_t N = env->N;
-    const size_t srow = (size_t)N * env->H * env->F;
+    const size_t srow = (size_t)N * env->H * env->F, crow = (size_t)N * 2 * env->V;
+    if (compact) PPO_TRY(env->obs_tmp.alloc(srow));           // per-step launches: the observation of one step only
     if (record_probs) PPO_TRY(ro->full_probs.alloc((size_t)T * N * env->A));
     // an env left terminal by a previous call starts a fresh episode (reset! before each episode)
     PPO_TRY(launch_env_reset(env, 1));
@@ -504,16 +549,17 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     if (ps == PPO_ERR_UNSUPPORTED) {
     PPO_TRY(disk_sink_begin(ro, T));
     for (int64_t t = 0; t < T; ++t) {
-        int8_t* st = ro->states.p + (size_t)t * srow;
+        int8_t* st = compact ? env->obs_tmp.p : ro->states.p + (size_t)t * srow;
         uint32_t* am = ro->active.p + (size_t)t * N;
         PPO_TRY(launch_env_observe(env, st, am));                                               // state(env)
+        if (compact) PPO_TRY(launch_env_snapshot(env, ro->cstate.p + (size_t)t * crow));       // what is kept of it
         PPO_TRY(launch_policy_rollout(pol, env, st, am, ro->actions.p + t * N, ro->p_sel.p + t * N,
                                       record_probs ? ro->full_probs.p + (size_t)t * N * env->A : nullptr));
         PPO_TRY(launch_env_step(env, ro->actions.p + t * N, ro->rewards.p + t * N, ro->done.p + t * N, nullptr, 1, 0));
         PPO_TRY(disk_sink_step(ro, t));                 // out-of-core store: async D2H of step t on the copy stream
     }
     }
-    ro->T = T;
+    ro->T = T; ro->adv_T = -1;
     PPO_TRY(set_index_all(ro));
     // compute_state_value!: returns overwrite the rewards column (src/rollout_buffer.jl:55-64)
     PPO_TRY(launch_returns_tn(ro->rewards.p, ro->done.p, ro->returns.p, T, N, discount, discount_is_f32));
@@ -534,17 +580,20 @@ int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_poli
     const int64_t N = env->N;
     const int64_t episodes_per_env = (num_episodes + N - 1) / N;       // the busiest env (env 0)
     const int64_t Tmax = episodes_per_env * env->max_actions;
-    PPO_TRY(rollouts_reserve(ro, Tmax));
-    const size_t srow = (size_t)N * env->H * env->F;
+    const bool compact = want_compact(ro, Tmax);
+    PPO_TRY(rollouts_reserve(ro, Tmax, compact));
+    const size_t srow = (size_t)N * env->H * env->F, crow = (size_t)N * 2 * env->V;
+    if (compact) PPO_TRY(env->obs_tmp.alloc(srow));
     hipLaunchKernelGGL(k_episode_quota, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, g_stream, env->episodes_left.p, N,
                        num_episodes);
     PPO_TRY(launch_env_reset(env, 0));                                  // reset!(env) before the first episode
     std::vector<int32_t> left((size_t)N);
     int64_t T = 0;
     for (int64_t t = 0; t < Tmax; ++t) {
-        int8_t* st = ro->states.p + (size_t)t * srow;
+        int8_t* st = compact ? env->obs_tmp.p : ro->states.p + (size_t)t * srow;
         uint32_t* am = ro->active.p + (size_t)t * N;
         PPO_TRY(launch_env_observe(env, st, am));
+        if (compact) PPO_TRY(launch_env_snapshot(env, ro->cstate.p + (size_t)t * crow));
         PPO_TRY(launch_policy_rollout(pol, env, st, am, ro->actions.p + t * N, ro->p_sel.p + t * N, nullptr));
         PPO_TRY(launch_env_step(env, ro->actions.p + t * N, ro->rewards.p + t * N, ro->done.p + t * N,
                                 ro->valid.p + t * N, 0, 1));
@@ -556,7 +605,7 @@ int32_t ppo_collect_rollouts_episodes(ppo_rollouts_t ro, ppo_env_t env, ppo_poli
             if (all) break;
         }
     }
-    ro->T = T;
+    ro->T = T; ro->adv_T = -1;
     // dataset order = env-major concatenation of whole episodes (the reference's flat buffer)
     std::vector<uint8_t> valid((size_t)T * N);
     PPO_TRY(d2h(valid.data(), ro->valid.p, (size_t)T * N));
@@ -621,7 +670,17 @@ RO_GETTER(ppo_rollouts_get_valid, valid, uint8_t, 1)
 
 int32_t ppo_rollouts_get_states(ppo_rollouts_t ro, int8_t* states, uint32_t* active) {
     ARG_CHECK(ro, "null");
-    if (states) PPO_TRY(d2h(states, ro->states.p, (size_t)ro->T * ro->N * ro->H * ro->F));
+    if (states && !ro->compact) PPO_TRY(d2h(states, ro->states.p, (size_t)ro->T * ro->N * ro->H * ro->F));
+    if (states && ro->compact) {       // compact form: the observations are re-derived on the device, <= 256 MiB at a time
+        const size_t per = (size_t)ro->H * ro->F, total = (size_t)ro->T * ro->N;
+        const size_t chunk = std::max<size_t>(1, std::min(total, ((size_t)256 << 20) / per));
+        PPO_TRY(ro->expand_tmp.alloc(chunk * per));
+        for (size_t o = 0; o < total; o += chunk) {
+            const size_t c = std::min(chunk, total - o);
+            PPO_TRY(launch_expand_states(ro->cstate.p + o * 2 * ro->V, ro->active.p + o, ro->tmpl.p, (int64_t)c, ro->V / 4, ro->expand_tmp.p));
+            PPO_TRY(d2h(states + o * per, ro->expand_tmp.p, c * per));
+        }
+    }
     if (active) PPO_TRY(d2h(active, ro->active.p, (size_t)ro->T * ro->N));
     return PPO_OK;
 }
@@ -641,19 +700,36 @@ int32_t ppo_rollouts_get_index(ppo_rollouts_t ro, int64_t* idx) {
 int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, const uint32_t* active,
                          const int32_t* actions0, const float* p_sel, const float* returns, const uint8_t* terminal) {
     ARG_CHECK(ro && T >= 1 && states && active && actions0 && p_sel && returns, "rollouts_set: bad argument");
-    PPO_TRY(rollouts_reserve(ro, T));
+    PPO_TRY(rollouts_reserve(ro, T, false));                  // host-supplied observations: always the expanded form
     const size_t n = (size_t)T * ro->N;
     PPO_TRY(h2d(ro->states.p, states, n * ro->H * ro->F)); PPO_TRY(h2d(ro->active.p, active, n));
     PPO_TRY(h2d(ro->actions.p, actions0, n)); PPO_TRY(h2d(ro->p_sel.p, p_sel, n)); PPO_TRY(h2d(ro->returns.p, returns, n));
     PPO_TRY(h2d(ro->rewards.p, returns, n));
     if (terminal) PPO_TRY(h2d(ro->done.p, terminal, n));
-    ro->T = T;
+    ro->T = T; ro->adv_T = -1;
     return set_index_all(ro);
+}
+
+// batch_advantage plugin as GAE(gamma, lambda): the state values come from the host (the reference has no value head;
+// a user's critic supplies them), the scan runs on the device over the buffer's raw rewards / terminal flags.
+int32_t ppo_rollouts_compute_gae(ppo_rollouts_t ro, const float* values, double gamma, double lambda, float* adv_out,
+                                 float* lambda_returns_out) {
+    ARG_CHECK(ro && values, "compute_gae: null argument");
+    ARG_CHECK(ro->T >= 1, "compute_gae: empty rollout buffer");
+    const size_t n = (size_t)ro->T * ro->N;
+    PPO_TRY(ro->values.alloc(n + ro->N)); PPO_TRY(ro->adv.alloc((size_t)ro->capT * ro->N)); PPO_TRY(ro->lam_ret.alloc((size_t)ro->capT * ro->N));
+    PPO_TRY(h2d(ro->values.p, values, n + ro->N));
+    PPO_TRY(launch_gae_tn(ro->rewards.p, ro->done.p, ro->values.p, ro->adv.p, ro->lam_ret.p, ro->T, ro->N, gamma, lambda));
+    ro->adv_T = ro->T;
+    if (adv_out) PPO_TRY(d2h(adv_out, ro->adv.p, n));
+    if (lambda_returns_out) PPO_TRY(d2h(lambda_returns_out, ro->lam_ret.p, n));
+    return PPO_OK;
 }
 
 // ================================================================ training
 // B = number of 32-row tiles of the minibatch (states * H/32)
-static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
+static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
+    if (compact) PPO_TRY(p->xs.alloc((size_t)std::max(B, p->cap_tiles) * 32 * p->F));
     if (B <= p->cap_tiles) return PPO_OK;
     const size_t NT = p->HID / 32;
     PPO_TRY(p->act1.alloc((size_t)B * NT * 1024)); PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
@@ -667,11 +743,15 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B) {
 // idx_dev: transition ids (already resolved through the dataset index)
 static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                     int64_t B_global, double eps, double ew, int32_t adv_mode) {
-    PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
+    PPO_TRY(train_reserve(pol, B * (ro->H / 32), ro->compact));
     const float* adv = ro->returns.p;                       // batch_advantage = returns (reference-equivalent)
-    if (adv_mode == PPO_ADV_RETURNS_NORMALISED) {           // normalised over this rank's minibatch
+    if (adv_mode == PPO_ADV_GAE || adv_mode == PPO_ADV_GAE_NORMALISED) {
+        ARG_CHECK(ro->adv.p && ro->adv_T == ro->T, "batch_advantage: GAE mode needs ppo_rollouts_compute_gae on these rollouts first");
+        adv = ro->adv.p;
+    }
+    if (adv_mode == PPO_ADV_RETURNS_NORMALISED || adv_mode == PPO_ADV_GAE_NORMALISED) {   // normalised over this rank's minibatch
         PPO_TRY(pol->adv_col.alloc((size_t)ro->capT * ro->N));
-        PPO_TRY(launch_adv_normalise(ro->returns.p, idx_dev, B, pol->adv_col.p));
+        PPO_TRY(launch_adv_normalise(adv, idx_dev, B, pol->adv_col.p));
         adv = pol->adv_col.p;
     }
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew, adv));
@@ -696,7 +776,7 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
     ARG_CHECK(B >= 1 && B <= ro->len, "step_batch!: 1 <= batch_size <= num_data (src/train.jl:88)");
     ARG_CHECK(B_global >= B, "step_batch!: B_global < B");
     ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "step_batch!: shape mismatch");
-    if (adv_mode != PPO_ADV_RETURNS && adv_mode != PPO_ADV_RETURNS_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
+    if (adv_mode < PPO_ADV_RETURNS || adv_mode > PPO_ADV_GAE_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
     for (int64_t i = 0; i < B; ++i) ARG_CHECK(sample_idx[i] >= 0 && sample_idx[i] < ro->len, "dataset index out of range (src/rollout_buffer.jl:105-106)");
     PPO_TRY(train_reserve(pol, B * (ro->H / 32)));
     DevBuf<int64_t> pos;
@@ -750,7 +830,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
     ARG_CHECK(world == 1 || allreduce, "ppo_train!: world > 1 needs an all-reduce hook");
     ARG_CHECK(pol->F == ro->F && (ro->H == 32 || ro->H == 128), "ppo_train!: shape mismatch");
     ARG_CHECK(batch_size >= 1, "1 <= batch_size <= num_data (src/train.jl:88)");
-    if (adv_mode != PPO_ADV_RETURNS && adv_mode != PPO_ADV_RETURNS_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
+    if (adv_mode < PPO_ADV_RETURNS || adv_mode > PPO_ADV_GAE_NORMALISED) { ppo_set_error("batch_advantage: unknown advantage mode"); return PPO_ERR_UNSUPPORTED; }
     // Data-parallel shards may differ in length (remainder envs, episode-mode rollouts): every rank learns every
     // rank's dataset length once per call -- an all-gather spelled as the hook's sum all-reduce over a one-hot
     // [2*world] vector (length split into two exactly representable floats) -- and derives from them the SAME

@@ -3,9 +3,12 @@
 // producing kernels by events, so the PCIe transfer of step t overlaps the kernels of step t+1; a writer
 // thread drains the pinned ring into one append-only file.
 //
-// File format (little endian): header {magic "PPOR", u32 version=1, i64 N, i32 H, i32 F, i32 A, i32 pad, i64 T}
-// then T step records  [states N*H*F i8][active N u32][actions N i32][p_sel N f32][rewards N f32][done N u8]
+// File format (little endian): header {magic "PPOR", u32 version, i64 N, i32 H, i32 F, i32 A, i32 V, i64 T}
+// then T step records  [states][active N u32][actions N i32][p_sel N f32][rewards N f32][done N u8]
 // then the returns column [T][N] f32 (written after compute_returns).
+//   version 1: states = the expanded observations, N*H*F int8 (2304 B per env-step for Q = 8)
+//   version 2: states = the env snapshots they are derived from, N*2V int8 (score[V] then degree[V]: 64 B for Q = 8) --
+//              the default while streaming (ppo_set_rollout_compact): 81 instead of 2321 bytes per env-step over PCIe
 #include "ppo_internal.h"
 #include <condition_variable>
 #include <cstdio>
@@ -16,7 +19,7 @@
 #include <dirent.h>
 #include <unistd.h>
 
-struct DiskHeader { char magic[4]; uint32_t version; int64_t N; int32_t H, F, A, pad; int64_t T; };
+struct DiskHeader { char magic[4]; uint32_t version; int64_t N; int32_t H, F, A, V; int64_t T; };
 
 struct DiskSink {
     std::string dir;
@@ -87,9 +90,12 @@ void disk_sink_destroy(DiskSink* s) {
 
 ppo_rollouts_s::~ppo_rollouts_s() { disk_sink_destroy(sink); sink = nullptr; }
 
-static size_t record_bytes(const ppo_rollouts_s* ro) {
+static size_t state_bytes(const ppo_rollouts_s* ro, bool compact) {
+    return (size_t)ro->N * (compact ? (size_t)2 * ro->V : (size_t)ro->H * ro->F);
+}
+static size_t record_bytes(const ppo_rollouts_s* ro, bool compact) {
     const size_t N = (size_t)ro->N;
-    return N * ro->H * ro->F + N * 4 * 4 + N;
+    return state_bytes(ro, compact) + N * 4 * 4 + N;
 }
 
 extern "C" int32_t ppo_rollouts_attach_disk(ppo_rollouts_t ro, const char* dir, int32_t pinned_slots) {
@@ -102,13 +108,8 @@ extern "C" int32_t ppo_rollouts_attach_disk(ppo_rollouts_t ro, const char* dir, 
     const std::string states = std::string(dir) + "/states";
     if (mkdir(states.c_str(), 0777) != 0) { ppo_set_error("DiskRollouts: cannot create states/"); return PPO_ERR_ARG; }
     DiskSink* s = new DiskSink();
-    s->dir = dir; s->slots = pinned_slots; s->rec_bytes = record_bytes(ro);
+    s->dir = dir; s->slots = pinned_slots; s->rec_bytes = 0;           // the pinned ring is sized in disk_sink_begin
     s->pinned.assign(pinned_slots, nullptr);
-    for (int i = 0; i < pinned_slots; ++i) {
-        if (hipHostMalloc((void**)&s->pinned[i], s->rec_bytes, hipHostMallocDefault) != hipSuccess) {
-            disk_sink_destroy(s); ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP;
-        }
-    }
     s->produced.resize(pinned_slots); s->copied.resize(pinned_slots);
     for (int i = 0; i < pinned_slots; ++i) {
         (void)hipEventCreateWithFlags(&s->produced[i], hipEventDisableTiming);
@@ -138,11 +139,18 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     }
     if (s->f) { fclose(s->f); s->f = nullptr; }
     s->enq = s->written = 0; s->stop = false; s->failed = false;
+    const size_t rec = record_bytes(ro, ro->compact);           // the storage form is decided per collection
+    if (rec != s->rec_bytes) {
+        for (char*& p : s->pinned) { if (p) (void)hipHostFree(p); p = nullptr; }
+        for (int i = 0; i < s->slots; ++i)
+            if (hipHostMalloc((void**)&s->pinned[i], rec, hipHostMallocDefault) != hipSuccess) { ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP; }
+        s->rec_bytes = rec;
+    }
     const std::string path = s->dir + "/rollout.bin";
     s->f = fopen(path.c_str(), "wb");
     if (!s->f) { ppo_set_error("DiskRollouts: cannot open " + path); return PPO_ERR_ARG; }
     DiskHeader h;
-    memcpy(h.magic, "PPOR", 4); h.version = 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.pad = 0; h.T = T;
+    memcpy(h.magic, "PPOR", 4); h.version = ro->compact ? 2 : 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.V = ro->V; h.T = T;
     if (fwrite(&h, sizeof(h), 1, s->f) != 1) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
     s->writer = std::thread(writer_loop, s);
     return PPO_OK;
@@ -157,11 +165,11 @@ int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t) {
         s->cv.wait(lk, [&] { return s->failed || s->written + s->slots > t; });
     }
     if (s->failed) { ppo_set_error("DiskRollouts: writer failed (disk full?)"); return PPO_ERR_ARG; }
-    const size_t N = (size_t)ro->N, sb = N * ro->H * ro->F;
+    const size_t N = (size_t)ro->N, sb = state_bytes(ro, ro->compact);
     HIP_TRY(hipEventRecord(s->produced[slot], ppo_stream()));
     HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->produced[slot], 0));
     char* dst = s->pinned[slot];
-    HIP_TRY(hipMemcpyAsync(dst, ro->states.p + (size_t)t * sb, sb, hipMemcpyDeviceToHost, s->copy_stream)); dst += sb;
+    HIP_TRY(hipMemcpyAsync(dst, (ro->compact ? ro->cstate.p : ro->states.p) + (size_t)t * sb, sb, hipMemcpyDeviceToHost, s->copy_stream)); dst += sb;
     HIP_TRY(hipMemcpyAsync(dst, ro->active.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
     HIP_TRY(hipMemcpyAsync(dst, ro->actions.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
     HIP_TRY(hipMemcpyAsync(dst, ro->p_sel.p + t * N, N * 4, hipMemcpyDeviceToHost, s->copy_stream)); dst += N * 4;
@@ -200,12 +208,13 @@ extern "C" int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir) {
     FILE* f = fopen(path.c_str(), "rb");
     ARG_CHECK(f != nullptr, "DiskDataset: trajectory file missing (src/dataset.jl:7)");
     DiskHeader h;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "PPOR", 4) != 0 || h.version != 1) {
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "PPOR", 4) != 0 || (h.version != 1 && h.version != 2)) {
         fclose(f); ppo_set_error("DiskDataset: bad header"); return PPO_ERR_ARG;
     }
-    if (h.N != ro->N || h.H != ro->H || h.F != ro->F) { fclose(f); ppo_set_error("DiskDataset: shape mismatch"); return PPO_ERR_ARG; }
+    const bool compact = h.version == 2;
+    if (h.N != ro->N || h.H != ro->H || h.F != ro->F || (compact && h.V != ro->V)) { fclose(f); ppo_set_error("DiskDataset: shape mismatch"); return PPO_ERR_ARG; }
     const int64_t T = h.T;
-    const size_t N = (size_t)ro->N, sb = N * ro->H * ro->F, rec = record_bytes(ro);
+    const size_t N = (size_t)ro->N, sb = state_bytes(ro, compact), rec = record_bytes(ro, compact);
     std::vector<char> buf(rec);
     std::vector<int8_t> st((size_t)T * sb);
     std::vector<uint32_t> act((size_t)T * N);
@@ -225,7 +234,21 @@ extern "C" int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir) {
     const bool have_ret = fread(ret.data(), 4, (size_t)T * N, f) == (size_t)T * N;
     fclose(f);
     ARG_CHECK(have_ret, "DiskDataset: returns column missing (collection did not finish)");
-    PPO_TRY(ppo_rollouts_set(ro, T, st.data(), act.data(), a0.data(), ps.data(), ret.data(), dn.data()));
+    if (!compact) {
+        PPO_TRY(ppo_rollouts_set(ro, T, st.data(), act.data(), a0.data(), ps.data(), ret.data(), dn.data()));
+    } else {                                      // env snapshots go back as they are: the buffer stays in the compact form
+        PPO_TRY(rollouts_reserve(ro, T, true));
+        const size_t n = (size_t)T * N;
+        hipStream_t s = ppo_stream();
+        HIP_TRY(hipMemcpyAsync(ro->cstate.p, st.data(), st.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ro->active.p, act.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ro->actions.p, a0.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ro->p_sel.p, ps.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ro->returns.p, ret.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ro->done.p, dn.data(), n, hipMemcpyHostToDevice, s));
+        ro->T = T; ro->adv_T = -1;
+        PPO_TRY(set_index_all(ro));
+    }
     HIP_TRY(hipMemcpyAsync(ro->rewards.p, rw.data(), (size_t)T * N * 4, hipMemcpyHostToDevice, ppo_stream()));
     HIP_TRY(hipStreamSynchronize(ppo_stream()));
     return PPO_OK;

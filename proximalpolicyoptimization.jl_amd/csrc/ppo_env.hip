@@ -103,6 +103,62 @@ __global__ void k_env_observe(EnvView e, int8_t* __restrict__ obs, uint32_t* __r
     reinterpret_cast<uint32_t*>(obs)[gid] = packed;
 }
 
+// compact rollout storage: record [2V] = score[V] then degree[V] of every env (one thread per dword)
+__global__ void k_env_snapshot(EnvView e, uint32_t* __restrict__ out) {
+    const int dv = e.V / 4;                                    // dwords per array
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = gid / (2 * dv);
+    if (n >= e.N) return;
+    const int d = (int)(gid - n * 2 * dv);
+    const int8_t* src = (d < dv) ? (e.score + n * e.V) : (e.degree + n * e.V);
+    out[gid] = reinterpret_cast<const uint32_t*>(src)[d < dv ? d : d - dv];
+}
+
+// state(env) from stored snapshots (getters / exporter of the compact form): same arithmetic as k_env_observe with the
+// score / degree bytes taken from record n of `cstate` instead of the live env arrays
+__global__ void k_expand_states(const int8_t* __restrict__ cstate, const uint32_t* __restrict__ active,
+                                const int8_t* __restrict__ tmpl, int64_t count, int Q, int8_t* __restrict__ obs) {
+    const int H = 4 * Q, F = 2 * PPO_TPL, V = 4 * Q;
+    const int dw_per_env = H * F / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = gid / dw_per_env;
+    if (n >= count) return;
+    const int rem = (int)(gid - n * dw_per_env);
+    const int h = rem / (F / 4), f0 = (rem % (F / 4)) * 4;
+    const uint32_t act = active[n];
+    const int8_t* src = cstate + n * 2 * V + ((f0 < PPO_TPL) ? 0 : V);
+    const int t0 = (f0 < PPO_TPL) ? f0 : f0 - PPO_TPL;
+    const bool own = (act >> (h >> 2)) & 1u;
+    const uint32_t ids = *reinterpret_cast<const uint32_t*>(tmpl + h * PPO_TPL + t0);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = (int)(int8_t)(ids >> (8 * i));
+        const bool ok = own && v >= 0 && ((act >> (v >> 2)) & 1u);
+        const int8_t val = ok ? src[v] : (int8_t)0;
+        packed |= ((uint32_t)(uint8_t)val) << (8 * i);
+    }
+    reinterpret_cast<uint32_t*>(obs)[gid] = packed;
+}
+
+int32_t launch_env_snapshot(ppo_env_s* e, int8_t* cstate_out) {
+    const int64_t total = e->N * (int64_t)(e->V / 2);
+    hipLaunchKernelGGL(k_env_snapshot, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppo_stream(), view_of(e),
+                       reinterpret_cast<uint32_t*>(cstate_out));
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+int32_t launch_expand_states(const int8_t* cstate, const uint32_t* active, const int8_t* tmpl, int64_t count, int32_t Q,
+                             int8_t* obs_out) {
+    if (count <= 0) return PPO_OK;
+    const int64_t total = count * (int64_t)(4 * Q * 2 * PPO_TPL / 4);
+    hipLaunchKernelGGL(k_expand_states, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppo_stream(), cstate, active,
+                       tmpl, count, (int)Q, obs_out);
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
 int32_t launch_env_reset(ppo_env_s* e, int only_done) {
     dim3 grid((unsigned)((e->N + 255) / 256));
     hipLaunchKernelGGL(k_env_reset, grid, dim3(256), 0, ppo_stream(), view_of(e), only_done);

@@ -92,6 +92,7 @@ struct ppo_policy_s {
     DevBuf<double> loss_terms;         // [tiles][2]
     DevBuf<float> slabs;               // [nwg][slab]
     DevBuf<int32_t> idx;               // gathered transition ids of the minibatch
+    DevBuf<int8_t> xs;                 // [tiles][32][F] state rows of the minibatch re-derived by the forward (compact rollouts)
     DevBuf<float> adv_col;             // batch_advantage scratch column [T*N] (PPO_ADV_RETURNS_NORMALISED)
     DevBuf<int32_t> err;               // device error flag
     int64_t cap_tiles = 0;
@@ -114,7 +115,16 @@ struct ppo_rollouts_s {
     int64_t N, capT, T;    // T = steps currently held
     int32_t H, F, A;
     int64_t len;           // valid transitions
-    DevBuf<int8_t> states;     // [T][N][H][F]
+    // state storage, one of two forms (ppo_set_rollout_compact):
+    //   expanded: the observation rows themselves, 2304 B per transition for Q = 8 (host-supplied rollouts always)
+    //   compact:  the env snapshot the rows are derived from (score[V] then degree[V], int8: 64 B for Q = 8) -- the
+    //             train forward re-derives the rows like the persistent rollout does (k_policy_fwd MODE 4)
+    bool compact = false;
+    int32_t V = 0;             // vertices per env (4Q)
+    DevBuf<int8_t> states;     // [T][N][H][F]        (expanded form)
+    DevBuf<int8_t> cstate;     // [T][N][2V]          (compact form)
+    DevBuf<int8_t> tmpl;       // [H][36] template vertex ids of the env the buffer was created for
+    DevBuf<int8_t> expand_tmp; // getters of the compact form: expanded observations, built on demand
     DevBuf<uint32_t> active;   // [T][N]
     DevBuf<int32_t> actions;   // [T][N]
     DevBuf<float> p_sel;       // [T][N]
@@ -124,10 +134,18 @@ struct ppo_rollouts_s {
     DevBuf<uint8_t> valid;     // [T][N]
     DevBuf<int32_t> index;     // [len] transition ids in dataset order
     DevBuf<float> full_probs;  // [T][N][A] optional
+    DevBuf<float> values;      // [T+1][N] host-supplied state values (ppo_rollouts_compute_gae)
+    DevBuf<float> adv;         // [T][N] GAE(gamma, lambda) advantages (PPO_ADV_GAE*)
+    DevBuf<float> lam_ret;     // [T][N] lambda-returns adv + V
+    int64_t adv_T = -1;        // T the adv column was computed for (-1: none)
     bool all_valid = true;
     DiskSink* sink = nullptr;  // optional out-of-core store (ppo_rollouts_attach_disk)
     ~ppo_rollouts_s();
 };
+
+// rollout buffer internals shared with the disk loader (ppo_api.hip)
+extern "C" int32_t rollouts_reserve(ppo_rollouts_s* r, int64_t T, bool compact);
+extern "C" int32_t set_index_all(ppo_rollouts_s* r);
 
 // out-of-core store hooks used by ppo_collect_rollouts (ppo_disk.hip)
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T);
@@ -152,6 +170,11 @@ int32_t launch_env_reset(ppo_env_s* e, int only_done);
 int32_t launch_env_step(ppo_env_s* e, const int32_t* actions_dev, float* reward_out, uint8_t* done_out,
                         uint8_t* valid_out, int auto_reset, int episodes_mode);
 int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out);
+// compact rollout storage: env snapshot of every env (score[V] then degree[V]) -> cstate_out [N][2V]
+int32_t launch_env_snapshot(ppo_env_s* e, int8_t* cstate_out);
+// snapshots -> observations (the same arithmetic as state(env)): count records of 2V bytes -> [count][H][F]
+int32_t launch_expand_states(const int8_t* cstate, const uint32_t* active, const int8_t* tmpl, int64_t count, int32_t Q,
+                             int8_t* obs_out);
 
 int32_t launch_pack_params(ppo_policy_s* p);
 int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uint32_t* active_dev, int64_t B,

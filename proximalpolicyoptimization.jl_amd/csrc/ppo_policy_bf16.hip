@@ -91,6 +91,9 @@ template <int F, int HID, int MODE, int TPS>
 __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
     using C = FwdB<F, HID>;
     constexpr int NT = C::NT, NS = C::NS, KS1 = C::KS1;
+    constexpr bool TRAIN = (MODE == 2 || MODE == 4);    // train forward: saves activations, loss tail
+    constexpr bool OBS = (MODE == 3 || MODE == 4);      // rows re-derived from an env snapshot in LDS (MODE 4: compact rollouts)
+    constexpr int TMODE = TRAIN ? 2 : MODE;
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) uint4 smem_u4[];
     uint4* const sW2 = smem_u4;
@@ -146,6 +149,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 *(PPO_LDS uint32_t*)r.done = a.env_done[n]; *r.episode = a.env_episode[n]; *r.tick = a.env_tick[n];
             }
         }
+    }
+    if (OBS) {
         if (TPS == 1) {
 #if PPO_BF16_TMPL_LDS
             // the 32 template rows (36 ids each) sit behind the env slots in LDS: nine registers less to carry through
@@ -161,30 +166,47 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    // MODE 4: env snapshot of a transition fetched through idx one state ahead (see k_policy_fwd)
+    uint32_t cs_next = 0u, act_next = 0u;
+    int32_t sid_next = 0;
+    auto fetch_snapshot = [&](int64_t state) {
+        sid_next = a.idx[state];
+        act_next = a.active[sid_next];
+        const int nd = a.envV >> 1;
+        cs_next = (lane < nd) ? reinterpret_cast<const uint32_t*>(a.cstate)[(size_t)sid_next * nd + lane] : 0u;
+    };
+    if (MODE == 4 && wave0 < a.B) fetch_snapshot(wave0);
     const int64_t t_steps = (MODE == 3) ? a.T : 1;
     FBSTAMP(0);
     for (int64_t tstep = 0; tstep < t_steps; ++tstep) {
     int slot = 0;
     for (int64_t state = wave0; state < a.B; state += nwaves, ++slot) {
-        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
+        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : ((MODE == 4) ? (int64_t)sid_next : state);
         EnvRefLds er = {};
         if (MODE == 3) er = slot_ref(slot);
-        const uint32_t act = (MODE == 3) ? *er.active : a.active[sid];
+        if (MODE == 4) {
+            er = slot_ref(0);
+            if (lane < (a.envV >> 1)) reinterpret_cast<PPO_LDS uint32_t*>(er.sc)[lane] = cs_next;
+            if (lane == 0) *er.active = act_next;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const uint32_t act = (MODE == 3) ? *er.active : ((MODE == 4) ? act_next : a.active[sid]);
+        if (MODE == 4) fetch_snapshot(state + nwaves < a.B ? state + nwaves : state);
         const uint32_t tick_val = (MODE == 3) ? *er.tick : ((MODE == 1) ? a.tick[state] : 0u);
         const int64_t out_index = (MODE == 3) ? tstep * a.B + state : state;
         float l[TPS][4];
 #pragma unroll
         for (int tt = 0; tt < TPS; ++tt) l[tt][0] = l[tt][1] = l[tt][2] = l[tt][3] = 0.0f;
         TailPre tpre = {0, 0.0f, 0.0f};
-        if (MODE == 2 && PPO_BF16_STORE_LATE) { tpre.ab = a.actions[sid]; tpre.po = a.p_old[sid]; tpre.adv = a.adv[sid]; }
+        if (TRAIN && PPO_BF16_STORE_LATE) { tpre.ab = a.actions[sid]; tpre.po = a.p_old[sid]; tpre.adv = a.adv[sid]; }
 #pragma unroll 1
         for (int ts = 0; ts < TPS; ++ts) {
             const int64_t tile = state * TPS + ts;
             // ---- state rows -> layer-1 B operands: lane (row j, half h) holds features 16s + 8h .. +7 of k-step s
-            const int8_t* row = a.states + ((size_t)sid * TPS + ts) * 32 * F + (size_t)j * F;
-            uint32_t ob[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3: this lane's 36 observed features (half h of row j)
-            if (MODE == 3) {
-                static_assert(MODE != 3 || F == 72, "the built-in env has F = 72 features");
+            const int8_t* row = OBS ? nullptr : a.states + ((size_t)sid * TPS + ts) * 32 * F + (size_t)j * F;
+            uint32_t ob[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3 / 4: this lane's 36 observed features (half h of row j)
+            if (OBS) {
+                static_assert(!OBS || F == 72, "the built-in env has F = 72 features");
                 uint32_t tid9[9];
                 if (TPS == 1) {
 #pragma unroll
@@ -200,16 +222,22 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                     for (int k = 0; k < 9; ++k) tid9[k] = tp[k];
                 }
                 env_observe_lane(er, tid9, 32 * ts + j, h, ob);
-                uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + ((size_t)out_index * TPS + ts) * 32 * F + (size_t)j * F + (size_t)h * 36);
+                int8_t* const rows_out = (MODE == 4) ? a.xs_out : a.states_out;
+                if (rows_out) {                                  // wave-uniform
+                    uint32_t* so = reinterpret_cast<uint32_t*>(rows_out + ((size_t)(MODE == 4 ? state : out_index) * TPS + ts) * 32 * F + (size_t)j * F + (size_t)h * 36);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) so[k] = ob[k];
+                    for (int k = 0; k < 9; ++k) so[k] = ob[k];
+                }
+                if (MODE == 3 && ts == 0 && a.cstate_out && lane < (a.envV >> 1))      // compact storage: the env snapshot itself
+                    reinterpret_cast<uint32_t*>(a.cstate_out)[(size_t)out_index * (a.envV >> 1) + lane] =
+                        reinterpret_cast<PPO_LDS uint32_t*>(er.sc)[lane];
             }
             uint4 xs[KS1];
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
                 const int off = 16 * s + 8 * h;
                 uint2 d = make_uint2(0u, 0u);
-                if (MODE == 3) {
+                if (OBS) {
                     // layer-1 k-step s wants features [16s + 8h, +8) of row j; the row's features sit 36 per lane half
                     // (lane j: 0..35, lane j + 32: 36..71) as 9 dwords each: pull the two dwords from the lane half that
                     // observed them.  Source half and dword index are compile-time per (s, destination half).
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
                     pack_tile(acc, h1p[o]);
-                    if (MODE == 2 && !PPO_BF16_STORE_LATE) {
+                    if (TRAIN && !PPO_BF16_STORE_LATE) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
                     }
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 // saved layer-1 activations leave AFTER the last W1 fragment has been waited for: loads and stores share
                 // the in-order vmcnt queue, so a store between two ring loads puts its HBM round trip on the MFMA chain
                 // (layer 2 takes its operands from LDS and never waits on vmcnt)
-                if (MODE == 2 && PPO_BF16_STORE_LATE) {
+                if (TRAIN && PPO_BF16_STORE_LATE) {
 #pragma unroll
                     for (int o = 0; o < NT; ++o) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
                 uint4 h2p[2];
                 pack_tile(acc, h2p);
-                if (MODE == 2) {
+                if (TRAIN) {
                     act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + lane, h2p[0]);
                     act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + 64 + lane, h2p[1]);
                 }
@@ -321,8 +349,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) l[tt][i] = (tt == ts) ? lg[i] : l[tt][i];
         }
-        const int sampled = policy_tail<MODE, TPS, true>(a, state, sid, act, l, lane, j, h, tick_val, out_index,
-                                                         (MODE == 2 && PPO_BF16_STORE_LATE) ? &tpre : nullptr);
+        const int sampled = policy_tail<TMODE, TPS, true>(a, state, sid, act, l, lane, j, h, tick_val, out_index,
+                                                          (TRAIN && PPO_BF16_STORE_LATE) ? &tpre : nullptr);
         FBSTAMP(4);
         if (MODE == 3) {
             asm volatile("" ::: "memory");
@@ -388,12 +416,13 @@ static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
 #define LAUNCHB(FF, HH, TT)                                                                                          \
     do {                                                                                                             \
-        const size_t lds = FwdB<FF, HH>::lds_bytes;                                                                  \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
+        /* MODE 4: one env-snapshot slot per wave + the template rows behind them */                               \
+        const size_t lds = FwdB<FF, HH>::lds_bytes + (MODE == 4 ? (size_t)8 * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
+        static size_t attr_lds = 0;                                                                                  \
+        if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<FF, HH, MODE, TT>,                            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-            attr_set = true;                                                                                         \
+            attr_lds = lds;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((k_policy_fwd_bf16<FF, HH, MODE, TT>), dim3(grid), dim3(512), lds, ppo_stream(), args);   \
     } while (0)
@@ -441,6 +470,7 @@ int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& a, int mode, int64_t B,
     a.act1b = (uint4*)p->act1.p; a.act2b = (uint4*)p->act2.p;
     if (mode == 0) return dispatch_fwd_bf16<0>(p, a, B, tps);
     if (mode == 1) return dispatch_fwd_bf16<1>(p, a, B, tps);
+    if (mode == 4) return dispatch_fwd_bf16<4>(p, a, B, tps);
     return dispatch_fwd_bf16<2>(p, a, B, tps);
 }
 
@@ -448,6 +478,7 @@ int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& a, int mode, int64_t B,
 struct BwdBArgs {
     const int8_t* states; const int32_t* idx; int32_t B;   // B = number of 32-row tiles (states * tps), < 2^31
     int tps_shift;                                          // tiles per state = 1 << tps_shift (H = 32 or 128)
+    int x_by_tile;                                          // 1: `states` is the forward's row scratch in minibatch order (compact rollouts)
     int nwg;                                                // == gridDim.x (as an argument: no dispatch-packet reload in the loop)
     const uint4* act1b; const uint4* act2b; const float4* dY;
     const uint4* w2tb; const uint2* w3tb;
@@ -604,7 +635,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16);
         }
         ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
-        const char* xs = reinterpret_cast<const char*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
+        const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
             const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
@@ -622,7 +653,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         } else if (k == 4 * FT) {
             ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
         } else if (k == 4 * FT + 1) {
-            const char* xs = reinterpret_cast<const char*>(a.states + (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1))) * 32 * F);
+            const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
             for (int i = 0; i < XPD; ++i) {
                 const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
@@ -953,7 +984,8 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     const int tps = ro->H / 32;
     ARG_CHECK((tps == 1 || tps == 4) && B * tps < ((int64_t)1 << 30), "bf16 backward: H must be 32 or 128 and the minibatch below 2^30 tiles");
     a.tps_shift = (tps == 4) ? 2 : 0;
-    a.states = ro->states.p; a.idx = idx_dev; a.B = (int32_t)(B * tps);
+    a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
+    a.idx = idx_dev; a.B = (int32_t)(B * tps);
     a.act1b = (const uint4*)p->act1.p; a.act2b = (const uint4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tb = (const uint4*)p->w2tb.p; a.w3tb = (const uint2*)p->w3tb.p;
     // the fp32 mode's activation buffers are twice the size the bf16 activations need: the operand fragments for the

@@ -42,6 +42,8 @@ struct BwdArgs {
 
     const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
     int tps;                                                // tiles per state (H / 32)
+    int x_by_tile;                                          // 1: `states` is the forward's row scratch in minibatch order
+                                                            //    (tile t's rows at t*32*F: compact rollouts); 0: gather by idx
     const float4* act1; const float4* act2; const float4* dY;
     const float4* w2tp; const float4* w3p;
     float* slabs; size_t slab_stride;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
 #endif
         }
         dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
-        const char* xs = reinterpret_cast<const char*>(a.states + ((size_t)sidx * a.tps + (size_t)(t % a.tps)) * 32 * F);
+        const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
             const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         }
     };
     if ((int64_t)blockIdx.x < a.B)
-        issue_tile_loads(blockIdx.x, __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
+        issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
 #ifdef PPO_BWD_STAMP
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #define STAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
@@ -384,9 +386,11 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
         {
             // next tile's transition id through the scalar cache (s_load + lgkmcnt): a vector load here would be
             // waited for with vmcnt(0), which also drains the pending LDS-DMA (a full HBM round trip)
-            const int32_t* ip = a.idx + ntile / a.tps;
-            int nidx;
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nidx) : "s"(ip) : "memory");
+            int nidx = 0;
+            if (!a.x_by_tile) {                                  // wave-uniform
+                const int32_t* ip = a.idx + ntile / a.tps;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nidx) : "s"(ip) : "memory");
+            }
             issue_tile_loads(ntile, nidx);
         }
         STAMP(8);
@@ -474,7 +478,8 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_bwd_bf16(p, ro, idx_dev, B);
     BwdArgs a;
     a.tps = ro->H / 32;
-    a.states = ro->states.p; a.idx = idx_dev; a.B = B * a.tps;
+    a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
+    a.idx = idx_dev; a.B = B * a.tps;
     a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int PFW = (PPO_FWD_PF < HID / 8) ? PPO_FWD_PF : HID / 8;     // at most the groups of one output tile
     // two waves per SIMD (HID = 128, F = 72): 4 groups cover the L2 latency; the train forward, whose activation stores
     // sit in the same vmcnt queue, wants the deep ring here too (0.072 -> 0.069 ms), the rollout does not (8.3 -> 8.7 ms)
-    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : ((MODE == 2) ? PFW : 4);   // weight-fragment groups kept in flight per wave
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : ((MODE == 2 || MODE == 4) ? PFW : 4);   // weight-fragment groups kept in flight per wave
+    constexpr bool TRAIN = (MODE == 2 || MODE == 4);    // train forward: saves activations, loss tail
+    constexpr bool OBS = (MODE == 3 || MODE == 4);      // the state rows are re-derived from an env snapshot in LDS
+    constexpr int TMODE = TRAIN ? 2 : MODE;             // policy_tail's mode
     static_assert(F % 8 == 0 && HID % 32 == 0, "shape");
     static_assert(PF * 64 * 4 <= PPO_PACK_PAD, "the ring reads PF groups past the end of a packed weight stream: padding must cover it");
     const int lane = threadIdx.x & 63;
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 
     // the rows of the NEXT 32-row tile are fetched while the current one computes (the gather through idx is two
     // dependent HBM round trips that one wave per SIMD cannot hide otherwise)
-    constexpr bool PFX = (FwdCfg<F, HID>::WPS == 1) && MODE != 3;   // with two waves per SIMD the partner wave hides it instead;
-                                                                  // MODE 3 computes the rows itself (no fetch)
+    constexpr bool PFX = (FwdCfg<F, HID>::WPS == 1) && !OBS;      // with two waves per SIMD the partner wave hides it instead;
+                                                                  // MODE 3 / 4 compute the rows themselves (no fetch)
     uint32_t xw[XW];
     auto fetch_rows = [&](int64_t state, int ts) {
         const int64_t sidn = (MODE == 2) ? (int64_t)a.idx[state] : state;
@@ -130,20 +133,39 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slots are wave-private: program order + in-order LDS suffice
     }
-    uint32_t tmpl_regs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3, TPS == 1: this lane's 36 template vertex ids
-    if (MODE == 3 && TPS == 1) {
+    uint32_t tmpl_regs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // MODE 3 / 4, TPS == 1: this lane's 36 template vertex ids
+    if (OBS && TPS == 1) {
         const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
 #pragma unroll
         for (int k = 0; k < 9; ++k) tmpl_regs[k] = tp[k];
     }
+    // MODE 4: the env snapshot of a transition (2V bytes + the active-quad word) is fetched through idx one state ahead
+    // (two dependent HBM round trips) into registers and parked in the wave's LDS slot at the top of its state
+    // (one dword per lane: 2V/4 <= 64 dwords for V <= 128)
+    uint32_t cs_next = 0u, act_next = 0u;
+    int32_t sid_next = 0;
+    auto fetch_snapshot = [&](int64_t state) {
+        sid_next = a.idx[state];
+        act_next = a.active[sid_next];
+        const int nd = a.envV >> 1;                              // dwords of one snapshot
+        cs_next = (lane < nd) ? reinterpret_cast<const uint32_t*>(a.cstate)[(size_t)sid_next * nd + lane] : 0u;
+    };
+    if (MODE == 4 && wave < a.B) fetch_snapshot(wave);
     const int64_t t_steps = (MODE == 3) ? a.T : 1;
     for (int64_t tt = 0; tt < t_steps; ++tt) {
     int slot = 0;
     for (int64_t state = wave; state < a.B; state += nwaves, ++slot) {
-        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : state;
+        const int64_t sid = (MODE == 2) ? (int64_t)a.idx[state] : ((MODE == 4) ? (int64_t)sid_next : state);
         EnvRefLds er = {};
         if (MODE == 3) er = slot_ref(slot);
-        const uint32_t act = (MODE == 3) ? *er.active : a.active[sid];
+        if (MODE == 4) {
+            er = slot_ref(0);
+            if (lane < (a.envV >> 1)) reinterpret_cast<PPO_LDS uint32_t*>(er.sc)[lane] = cs_next;
+            if (lane == 0) *er.active = act_next;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slot: program order + in-order LDS suffice
+        }
+        const uint32_t act = (MODE == 3) ? *er.active : ((MODE == 4) ? act_next : a.active[sid]);
+        if (MODE == 4) fetch_snapshot(state + nwaves < a.B ? state + nwaves : state);      // lands under this state's MFMAs
         const uint32_t tick_val = (MODE == 3) ? *er.tick : ((MODE == 1) ? a.tick[state] : 0u);
         const int64_t out_index = (MODE == 3) ? tt * a.B + state : state;
         float l[TPS][4];
@@ -159,9 +181,10 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             int lane_o = lane, half_o = h;
             asm volatile("" : "+v"(lane_o), "+v"(half_o));
             // ---- state rows -> B operands of layer 1: lane half 0 holds features [0,F/2), half 1 [F/2,F)
-            if (MODE == 3) {
+            if (OBS) {
                 // state(env): this lane's 36 features of half-edge row 32*ts + j, recorded into the rollout buffer
-                static_assert(MODE != 3 || XW == 9, "the built-in env has F = 72 features");
+                // (MODE 3, expanded storage) or into the minibatch-ordered row scratch the backward reads (MODE 4)
+                static_assert(!OBS || XW == 9, "the built-in env has F = 72 features");
                 uint32_t ob[9], tid[9];
                 if (TPS == 1) {
 #pragma unroll
@@ -172,10 +195,18 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     for (int k = 0; k < 9; ++k) tid[k] = tp[k];
                 }
                 env_observe_lane(er, tid, 32 * ts + j, h, ob);
-                uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + ((size_t)out_index * TPS + ts) * 32 * F +
-                                                           (size_t)j * F + (size_t)h * XB);
 #pragma unroll
-                for (int k = 0; k < XW; ++k) { xw[k] = ob[k < 9 ? k : 0]; so[k] = xw[k]; }
+                for (int k = 0; k < XW; ++k) xw[k] = ob[k < 9 ? k : 0];
+                int8_t* const rows_out = (MODE == 4) ? a.xs_out : a.states_out;
+                if (rows_out) {                                  // wave-uniform
+                    uint32_t* so = reinterpret_cast<uint32_t*>(rows_out + ((size_t)(MODE == 4 ? state : out_index) * TPS + ts) * 32 * F +
+                                                               (size_t)j * F + (size_t)h * XB);
+#pragma unroll
+                    for (int k = 0; k < XW; ++k) so[k] = xw[k];
+                }
+                if (MODE == 3 && ts == 0 && a.cstate_out && lane < (a.envV >> 1))      // compact storage: the env snapshot itself
+                    reinterpret_cast<uint32_t*>(a.cstate_out)[(size_t)out_index * (a.envV >> 1) + lane] =
+                        reinterpret_cast<PPO_LDS uint32_t*>(er.sc)[lane];
             } else if (!PFX) fetch_rows(state, ts);
             float xf[XB];
 #pragma unroll
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
                     h1[o] = acc;
-                    if (MODE == 2 && PPO_FWD_STORE) {
+                    if (TRAIN && PPO_FWD_STORE) {
                         float4* dst = a.act1 + ((size_t)tile * NT + o) * 4 * 64;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     asm volatile("" : "+v"(acc));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
-                    if (MODE == 2 && PPO_FWD_STORE) {
+                    if (TRAIN && PPO_FWD_STORE) {
                         float4* dst = a.act2 + ((size_t)tile * NT + o) * 4 * 64;
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -303,7 +334,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
         }
 
         FSTAMP(4);
-        const int sampled = policy_tail<MODE, TPS, false>(a, state, sid, act, l, lane, j, h, tick_val, out_index);
+        const int sampled = policy_tail<TMODE, TPS, false>(a, state, sid, act, l, lane, j, h, tick_val, out_index);
         if (MODE == 3) {
             // update!: the observed mask, then step!(env, a), reward, is_terminal (src/collect_rollouts.jl:9-14) and the
             // reset! before the next episode (src/rollout_buffer.jl:75) -- one lane, on the LDS slot
@@ -373,7 +404,12 @@ static int32_t dispatch_fwd(ppo_policy_s* p, const FwdArgs& args, int64_t B, int
         const int64_t cap = 256 * FwdCfg<FF, HH>::WPS;                                                   \
         const unsigned grid = (unsigned)(need < cap ? need : cap);                                       \
         const_cast<FwdArgs&>(args).wg_sync = (B % ((int64_t)grid * 4) == 0) ? 1 : 0;                     \
-        hipLaunchKernelGGL((k_policy_fwd<FF, HH, MODE, TT>), dim3(grid), dim3(256), 0, ppo_stream(), args); \
+        if constexpr (MODE == 4 && FF != 72) {                                                             \
+            ppo_set_error("compact rollouts need the built-in env's F = 72"); return PPO_ERR_UNSUPPORTED;    \
+        } else {                                                                                             \
+            const size_t dlds = (MODE == 4) ? (size_t)4 * (2 * args.envV + 32) : 0;   /* one snapshot slot per wave */ \
+            hipLaunchKernelGGL((k_policy_fwd<FF, HH, MODE, TT>), dim3(grid), dim3(256), dlds, ppo_stream(), args); \
+        }                                                                                                    \
     } while (0)
     if (p->F == 72 && p->HID == 256 && tps == 1) LAUNCH(72, 256, 1);
     else if (p->F == 72 && p->HID == 256 && tps == 4) LAUNCH(72, 256, 4);
@@ -449,7 +485,8 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     a.env_reward = e->reward.p; a.env_done = e->done.p; a.env_episode = e->episode.p; a.env_tick = e->tick.p;
     a.env_tmpl = e->tmpl.p; a.envQ = e->Q; a.envV = e->V; a.env_max_actions = e->max_actions; a.env_slots = slots;
     a.env_nar = e->no_action_reward; a.err = e->err.p;
-    a.states_out = ro->states.p; a.active_out = ro->active.p; a.actions_out = ro->actions.p; a.psel_out = ro->p_sel.p;
+    a.states_out = ro->compact ? nullptr : ro->states.p; a.cstate_out = ro->compact ? ro->cstate.p : nullptr;
+    a.active_out = ro->active.p; a.actions_out = ro->actions.p; a.psel_out = ro->p_sel.p;
     a.rew_out = ro->rewards.p; a.done_out = ro->done.p;
     a.full_probs = record_probs ? ro->full_probs.p : nullptr;
     ProfScope ps("k_rollout_persistent");
@@ -483,6 +520,12 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
     a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = adv_col;
     a.eps = eps; a.c_over_B = (float)(entropy_weight / (double)B_global); a.inv_B = (float)(1.0 / (double)B_global);
     ProfScope ps("k_policy_fwd_train");
+    if (ro->compact) {      // rows are re-derived from the env snapshots and left in p->xs (minibatch order) for the backward
+        a.states = nullptr; a.cstate = ro->cstate.p; a.xs_out = p->xs.p;
+        a.env_tmpl = ro->tmpl.p; a.envV = ro->V; a.envQ = ro->V / 4; a.env_slots = 1;
+        if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 4, B, ro->H / 32);
+        return dispatch_fwd<4>(p, a, B, ro->H / 32);
+    }
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 2, B, ro->H / 32);
     return dispatch_fwd<2>(p, a, B, ro->H / 32);
 }

@@ -34,6 +34,10 @@ struct FwdArgs {
     uint8_t* env_done; uint32_t* env_episode; uint32_t* env_tick; const int8_t* env_tmpl;
     int32_t envQ, envV, env_max_actions, env_slots; float env_nar;
     int8_t* states_out; uint32_t* active_out; float* rew_out; uint8_t* done_out;      // rollout columns [T][N]
+    // compact rollout storage: an env snapshot (score[V] then degree[V], int8) per transition instead of the expanded
+    // [H][F] observation.  MODE 3 writes cstate_out (states_out may then be null); MODE 4 = MODE 2 (train forward) reading
+    // cstate through idx, re-deriving the rows like MODE 3 and leaving them in xs_out (minibatch order) for the backward
+    int8_t* cstate_out; const int8_t* cstate; int8_t* xs_out;
     // bf16 compute mode (ppo_policy_bf16.hip): bf16 fragment streams and bf16 saved activations
     const uint4* w1b; const uint4* w2b; const uint4* w3c; uint4* act1b; uint4* act2b;
 };
@@ -84,6 +88,7 @@ __device__ __forceinline__ float dy_round(float x) {
 struct TailPre { int ab; float po; float adv; };
 
 // l[ts][i]: logit of action 128*ts + 4*j + i of the state, present in both lane halves (j = lane & 31).
+// MODE 2 also serves the train forward from compact states (kernel MODE 4).
 // MODE 1 / 3 (rollout): tick_val = the env's tick (Philox counter word), out_index = position of the transition in
 // the output columns (state for one step, t*N + state for the persistent rollout); returns the sampled action.
 template <int MODE, int TPS, bool DYBF16>

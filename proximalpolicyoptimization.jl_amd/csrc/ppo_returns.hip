@@ -185,7 +185,15 @@ __global__ void k_returns_flat(const float* __restrict__ r, const uint8_t* __res
     }
 }
 
-// GAE(gamma, lambda) extension (no reference counterpart); one lane per column, fp64 running value.
+// GAE(gamma, lambda) extension: the `batch_advantage` plugin the reference declares (src/ProximalPolicyOptimization.jl:29)
+// and never implements; lambda = 1, V = 0 is exactly compute_returns (src/collect_rollouts.jl:26-42).  Recurrence per
+// column, latest row first, all in fp64 like the reference's running value:
+//     nd = !done[t];  delta = (r[t] + gamma * (V[t+1] * nd)) - V[t];  A = delta + ((gamma * lambda) * nd) * A
+//     adv[t] = float(A);  ret[t] = float(A + V[t])
+// HBM-bound: 17 B per transition (r f32 + done u8 + V f32 in, adv f32 + ret f32 out; V[t+1] is the V[t] of the row
+// scanned just before, carried in a register, so every value is read once).
+
+// small-N form: one lane per column (scalar, coalesced rows)
 __global__ void k_gae_tn(const float* __restrict__ r, const uint8_t* __restrict__ done, const float* __restrict__ val,
                          float* __restrict__ adv, float* __restrict__ ret, int64_t T, int64_t N, double gamma,
                          double lambda) {
@@ -193,15 +201,106 @@ __global__ void k_gae_tn(const float* __restrict__ r, const uint8_t* __restrict_
     if (n >= N) return;
     double a = 0.0;
     const double gl = gamma * lambda;
+    double vn = (double)val[T * N + n];
     for (int64_t t = T - 1; t >= 0; --t) {
         const double nd = done[t * N + n] ? 0.0 : 1.0;
-        const double vnext = (double)val[(t + 1) * N + n] * nd;
+        const double v = (double)val[t * N + n];
+        const double vnext = vn * nd;
         const double gvn = gamma * vnext;
-        const double delta = ((double)r[t * N + n] + gvn) - (double)val[t * N + n];
+        const double delta = ((double)r[t * N + n] + gvn) - v;
         const double carry = (gl * nd) * a;
         a = delta + carry;
         adv[t * N + n] = (float)a;
-        ret[t * N + n] = (float)(a + (double)val[t * N + n]);
+        ret[t * N + n] = (float)(a + v);
+        vn = v;
+    }
+}
+
+// Wide form for large N (N % 4 == 0), the LDS-staged structure of k_returns_tn_x4: a workgroup owns COLS adjacent
+// columns; per pass of RW_ROWS time rows every wave loads its share of the three input tiles with full-width accesses
+// (16 B per lane for r and V, 4 B for the done flags) into LDS; after a barrier wave w scans columns [64w, 64w+64)
+// -- one column per lane, the exact sequential fp64 recurrence, A and V[t+1] carried in registers across passes, no
+// cross-wave dependency -- writing adv over the r tile and ret over the V tile; after a second barrier both tiles
+// leave with wide stores.  Two tile sets are ping-ponged so the loads of pass p+1 are in flight during the scan of p.
+template <int COLS, int RW_ROWS>
+__global__ __launch_bounds__(COLS) void k_gae_tn_x4(const float* __restrict__ r, const uint8_t* __restrict__ done,
+                                                    const float* __restrict__ val, float* __restrict__ adv,
+                                                    float* __restrict__ ret, int64_t T, int64_t N, double gamma,
+                                                    double lambda) {
+    constexpr int W = COLS / 64, RS = 256 / COLS, RPW = RW_ROWS / (W * RS);
+    static_assert(RPW >= 1 && RPW * W * RS == RW_ROWS, "tile shape");
+    __shared__ __attribute__((aligned(16))) float sR[2][RW_ROWS][COLS];
+    __shared__ __attribute__((aligned(16))) float sV[2][RW_ROWS][COLS];
+    __shared__ __attribute__((aligned(16))) uint8_t sD[2][RW_ROWS][COLS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * COLS;
+    const int lr = lane / (COLS / 4), lc = (lane % (COLS / 4)) * 4;
+    const int64_t cl = c0 + lc;
+    const bool wide_ok = cl < N;                                // N % 4 == 0
+    const int64_t sc = c0 + 64 * w + lane;                      // this lane's scan column
+    const int64_t npass = (T + RW_ROWS - 1) / RW_ROWS;
+    const double gl = gamma * lambda;
+    double a = 0.0;
+    double vn = (sc < N) ? (double)val[T * N + sc] : 0.0;       // V[T]: bootstrap value behind the last row
+
+    float4 rv[RPW], vv[RPW];
+    uint32_t dv[RPW];
+    auto tile_row = [&](int i) { return (w * RPW + i) * RS + lr; };
+    auto load_regs = [&](int64_t p) {
+        const int64_t base = T - (int64_t)RW_ROWS * (p + 1);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int64_t t = base + tile_row(i);
+            rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); vv[i] = rv[i]; dv[i] = 0u;
+            if (wide_ok && t >= 0) {
+                rv[i] = *reinterpret_cast<const float4*>(r + t * N + cl);
+                vv[i] = *reinterpret_cast<const float4*>(val + t * N + cl);
+                dv[i] = *reinterpret_cast<const uint32_t*>(done + t * N + cl);
+            }
+        }
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            *reinterpret_cast<float4*>(&sR[buf][tile_row(i)][lc]) = rv[i];
+            *reinterpret_cast<float4*>(&sV[buf][tile_row(i)][lc]) = vv[i];
+            *reinterpret_cast<uint32_t*>(&sD[buf][tile_row(i)][lc]) = dv[i];
+        }
+    };
+    load_regs(0);
+    park(0);
+    __syncthreads();
+    for (int64_t p = 0; p < npass; ++p) {
+        const int buf = (int)(p & 1);
+        const int64_t base = T - (int64_t)RW_ROWS * (p + 1);
+        if (p + 1 < npass) load_regs(p + 1);
+#pragma unroll 8
+        for (int row = RW_ROWS - 1; row >= 0; --row) {
+            if (base + row < 0) break;
+            const double x = (double)sR[buf][row][64 * w + lane];
+            const double v = (double)sV[buf][row][64 * w + lane];
+            const double nd = sD[buf][row][64 * w + lane] ? 0.0 : 1.0;
+            const double vnext = vn * nd;
+            const double gvn = gamma * vnext;
+            const double delta = (x + gvn) - v;
+            const double carry = (gl * nd) * a;
+            a = delta + carry;
+            sR[buf][row][64 * w + lane] = (float)a;
+            sV[buf][row][64 * w + lane] = (float)(a + v);
+            vn = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = tile_row(i);
+            const int64_t t = base + row;
+            if (wide_ok && t >= 0) {
+                *reinterpret_cast<float4*>(adv + t * N + cl) = *reinterpret_cast<const float4*>(&sR[buf][row][lc]);
+                *reinterpret_cast<float4*>(ret + t * N + cl) = *reinterpret_cast<const float4*>(&sV[buf][row][lc]);
+            }
+        }
+        if (p + 1 < npass) park(buf ^ 1);
+        __syncthreads();
     }
 }
 
@@ -243,6 +342,15 @@ int32_t launch_returns_flat(const float* r, const uint8_t* term, float* out, int
 int32_t launch_gae_tn(const float* r, const uint8_t* done, const float* values, float* adv, float* ret, int64_t T,
                       int64_t N, double gamma, double lambda) {
     if (T <= 0 || N <= 0) return PPO_OK;
+    ProfScope ps("k_gae_tn");
+    if (N % 4 == 0 && N >= 16384) {                  // wide columns, LDS-staged (73.7 KB of LDS: two workgroups per CU)
+        const int cols = (N / 256 >= 1024) ? 256 : 128;
+        dim3 gridw((unsigned)((N + cols - 1) / cols));
+        if (cols == 256) hipLaunchKernelGGL((k_gae_tn_x4<256, 16>), gridw, dim3(256), 0, ppo_stream(), r, done, values, adv, ret, T, N, gamma, lambda);
+        else hipLaunchKernelGGL((k_gae_tn_x4<128, 16>), gridw, dim3(128), 0, ppo_stream(), r, done, values, adv, ret, T, N, gamma, lambda);
+        HIP_TRY(hipGetLastError());
+        return PPO_OK;
+    }
     dim3 grid((unsigned)((N + 63) / 64));
     hipLaunchKernelGGL(k_gae_tn, grid, dim3(64), 0, ppo_stream(), r, done, values, adv, ret, T, N, gamma, lambda);
     HIP_TRY(hipGetLastError());

@@ -123,8 +123,16 @@ def _dataset(P, N, T, HID, seed, Q=8):
     return env, pol, ro, P.construct_dataset(ro)
 
 
+@pytest.fixture(params=[False, True], ids=["expanded", "compact"])
+def storage_mode(request, P):
+    """Expanded observation rows vs env snapshots re-derived by the train forward (ppo_set_rollout_compact)."""
+    P.set_rollout_compact(request.param)
+    yield request.param
+    P.set_rollout_compact(None)
+
+
 @pytest.mark.parametrize("HID,B,Q", [(128, 24, 8), (128, 300, 8), (256, 40, 8), (256, 520, 8), (256, 30, 32), (128, 30, 32)])
-def test_bf16_gradient_vs_oracle(P, npo, HID, B, Q):
+def test_bf16_gradient_vs_oracle(P, npo, HID, B, Q, storage_mode):
     N, T, H = 40, 16, 4 * Q
     env, pol, ro, ds = _dataset(P, N, T, HID, seed=B + Q, Q=Q)
     rng = np.random.default_rng(B)

@@ -61,9 +61,12 @@ def test_returns_rel_tolerance_vs_pure_f32(P):
     assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
-def test_gae(P, orc):
-    rng = np.random.default_rng(5)
-    T, N = 77, 130
+@pytest.mark.parametrize("T,N", [(77, 130), (1, 1), (128, 16384), (45, 16388), (33, 65536), (16, 262144)])
+def test_gae(P, orc, T, N):
+    """GAE(gamma, lambda) scan, both kernels (one lane per column below 16384 columns, the LDS-tiled wide form above:
+    128- and 256-column workgroups, ragged last pass, partly filled last workgroup): bit-exact against the fp64 oracle;
+    lambda = 1, V = 0 is compute_returns (src/collect_rollouts.jl:26-42) bit for bit."""
+    rng = np.random.default_rng(T + N)
     r = rng.normal(size=(T, N)).astype(np.float32)
     d = (rng.random((T, N)) < 0.05).astype(np.uint8)
     v = rng.normal(size=(T + 1, N)).astype(np.float32)
@@ -72,6 +75,54 @@ def test_gae(P, orc):
     assert np.array_equal(adv, oadv) and np.array_equal(ret, oret)
     adv1, _ = P.gae_tn(r, d, np.zeros_like(v), 0.99, 1.0)           # lambda=1, V=0 == returns
     assert np.array_equal(adv1, P.compute_returns_tn(r, d, 0.99))
+    assert np.array_equal(adv1, orc.compute_returns_tn(r, d, 0.99))
+
+
+def test_gae_advantage_mode_in_training(P, orc):
+    """batch_advantage = GAE (PPO_ADV_GAE): values from the host, scan on the device over the buffer's own raw rewards,
+    the advantage column consumed by the fused loss.  Gradient vs the float64 oracle fed with the oracle's GAE column;
+    with lambda = 1, V = 0 the mode reproduces the returns mode bit for bit."""
+    env = P.HipVecEnv(num_envs=24, Q=8, max_actions=9, seed=8)
+    pol = P.HipPolicy(72, 128, 2, 4, seed=6)
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, 12, 0.97)
+    ds = P.construct_dataset(ro)
+    T, N = ro.dims()
+    sel = np.random.default_rng(3).permutation(len(ds))[:150] + 1
+    with pytest.raises(P.PPOError, match="compute_gae"):
+        P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="gae")
+    values = np.random.default_rng(4).normal(size=(T + 1, N)).astype(np.float32)
+    adv, lret = P.compute_gae_(ro, values, 0.97, 0.9)
+    oadv, oret = orc.gae_tn(ro.raw_rewards, ro.terminal.astype(np.uint8), values, 0.97, 0.9)
+    assert np.array_equal(adv, oadv) and np.array_equal(lret, oret)
+    st, act = ro.state_data
+    s0 = sel - 1
+    cols = (st.reshape(-1, 32, 72)[s0], act.reshape(-1)[s0], (ro.selected_actions.reshape(-1)[s0] - 1).astype(np.int32),
+            ro.selected_action_probabilities.reshape(-1)[s0])
+    for mode, a in (("gae", oadv.reshape(-1)[s0]),
+                    ("gae_normalised", None)):
+        if a is None:
+            x = oadv.reshape(-1)[s0].astype(np.float64)
+            a = ((x - x.mean()) / (x.std() + 1e-8)).astype(np.float32)
+        lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage=mode)
+        g64, olp, ole = orc.step_batch_grad_f64(pol.params, 72, 128, *cols, a, 0.05, 0.01)
+        assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+        assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    # lambda = 1, V = 0: the GAE column IS the returns column
+    adv1, _ = P.compute_gae_(ro, np.zeros((T + 1, N), np.float32), 0.97, 1.0)
+    assert np.array_equal(adv1, ro.rewards)
+    P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="gae")
+    g_gae = pol.grad()
+    P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="returns")
+    assert np.array_equal(g_gae, pol.grad())
+    # a whole ppo_train! epoch in GAE mode runs and moves the parameters
+    before = pol.params.copy()
+    P.ppo_train_(pol, P.Optimiser(P.Adam(1e-3)), ds, 0.05, 64, 1, 0.01, seed=3, verbose=False, advantage="gae")
+    assert not np.array_equal(before, pol.params) and np.all(np.isfinite(pol.params))
+    # new rollouts invalidate the column
+    P.collect_rollouts_steps_(ro, env, pol, 12, 0.97)
+    with pytest.raises(P.PPOError, match="compute_gae"):
+        P.forward_backward(pol, P.construct_dataset(ro), sel, 0.05, 0.01, advantage="gae")
 
 
 # ---------------------------------------------------------------- RNG / sampling / index ops
@@ -208,7 +259,7 @@ def test_policy_forward(P, orc, golden_dir, F, HID, fixture):
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
 @pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10)])
-def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode):
+def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_mode):
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=max_actions, seed=77, global_offset=5)
     pol = P.HipPolicy(72, HID, 2, 4, seed=11)
     ro = P.BufferRollouts()
@@ -240,8 +291,17 @@ def rollout_mode(request, P):
     P.set_rollout_persistent(None)
 
 
+@pytest.fixture(params=[False, True], ids=["expanded", "compact"])
+def storage_mode(request, P):
+    """Both state-storage forms of engine-collected rollouts: the expanded observation rows, and the env snapshots the
+    train forward re-derives them from (ppo_set_rollout_compact)."""
+    P.set_rollout_compact(request.param)
+    yield request.param
+    P.set_rollout_compact(None)
+
+
 @pytest.mark.parametrize("case", range(10))
-def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode):
+def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode, storage_mode):
     """Randomised shapes / seeds / horizons / global offsets: whole rollouts stay bit-identical to the device-order
     oracle (states, masks, sampled actions, probabilities, rewards, done flags, returns in both discount types)."""
     rng = np.random.default_rng(1000 + case)
@@ -272,7 +332,7 @@ def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 31, 33, 255, 257])
-def test_gradient_ragged_batch_sizes(P, orc, B):
+def test_gradient_ragged_batch_sizes(P, orc, B, storage_mode):
     """Minibatches that do not fill the persistent grid (B = 1 ... 257 tiles on 256 workgroups) and repeat samples."""
     env, pol, ro, ds = _make_dataset(P, orc, 30, 10, 256, seed=77)      # 300 samples
     rng = np.random.default_rng(B)
@@ -378,7 +438,7 @@ def _oracle_grad(orc, pol_params, HID, ro, sel0, eps, ew):
 
 
 @pytest.mark.parametrize("HID,B", [(128, 24), (128, 300), (256, 40), (256, 520)])
-def test_gradient_vs_f64_oracle(P, orc, HID, B):
+def test_gradient_vs_f64_oracle(P, orc, HID, B, storage_mode):
     N, T = 40, 16
     env, pol, ro, ds = _make_dataset(P, orc, N, T, HID, seed=B)
     rng = np.random.default_rng(B)
@@ -454,7 +514,7 @@ def test_normalised_advantage_mode(P, orc):
         assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
         assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
     with pytest.raises(P.PPOError):
-        P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="gae")
+        P.forward_backward(pol, ds, sel, 0.05, 0.01, advantage="td0")
     # a whole ppo_train! epoch in this mode runs and changes the parameters
     before = pol.params.copy()
     P.ppo_train_(pol, P.Optimiser(P.Adam(1e-3)), ds, 0.05, 64, 1, 0.01, seed=3, verbose=False, advantage="returns_normalised")
@@ -485,7 +545,7 @@ def test_step_batch_adam_bitexact(P, orc):
         P.get_optimizer_learning_rate(P.Adam(1e-4))          # a bare Adam is not iterable (src/train.jl:155-158)
 
 
-def test_ppo_train_epochs_with_explicit_perm(P, orc):
+def test_ppo_train_epochs_with_explicit_perm(P, orc, storage_mode):
     """ppo_train! (src/train.jl:86-153) with explicitly supplied permutations (stand-in for randperm):
     per-epoch mean losses and final parameters vs the oracle loop (f64 grad -> f32 -> oracle Adam)."""
     env, pol, ro, ds = _make_dataset(P, orc, 12, 10, 128, seed=21)
@@ -592,7 +652,7 @@ def test_policy_forward_q32(P, orc):
 
 
 @pytest.mark.parametrize("HID", [128, 256])
-def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode):
+def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode, storage_mode):
     """square_mesh-sized action space (Q=32 quads, 512 masked actions), variable-length episodes."""
     N, T, max_actions = 12, 20, 9
     env = P.HipVecEnv(num_envs=N, Q=32, max_actions=max_actions, seed=31)
@@ -740,9 +800,21 @@ def test_write_returns_to_disk_reproduces_reference_csv(P, golden_dir, tmp_path)
     assert len(ds) == 6 and ds[1]["returns"] == 6.0 and ds[6]["returns"] == 1.0
 
 
-def test_streamed_disk_rollouts_roundtrip(P, orc, tmp_path):
+@pytest.mark.parametrize("stream_form", ["compact", "expanded"])
+def test_streamed_disk_rollouts_roundtrip(P, orc, tmp_path, stream_form):
     """Steps are streamed device -> pinned host -> rollout.bin while collection runs; the shard read back through
-    ppo_rollouts_load_disk must reproduce every column, and training from it must match training from memory."""
+    ppo_rollouts_load_disk must reproduce every column, and training from it must match training from memory.  Default
+    while streaming: the record carries the 64-byte env snapshot instead of the 2304-byte observation (file version 2);
+    ppo_set_rollout_compact(0) keeps the observation rows (version 1)."""
+    if stream_form == "expanded":
+        P.set_rollout_compact(False)
+    try:
+        _streamed_roundtrip(P, tmp_path, 32 * 72 if stream_form == "expanded" else 64)
+    finally:
+        P.set_rollout_compact(None)
+
+
+def _streamed_roundtrip(P, tmp_path, state_bytes):
     N, T = 48, 12
     res = {}
     for mode in ("memory", "disk"):
@@ -755,7 +827,7 @@ def test_streamed_disk_rollouts_roundtrip(P, orc, tmp_path):
             disk = P.DiskRollouts(str(tmp_path / "store"))
             P.collect_rollouts_steps_(disk, env, pol, T, 0.99, pinned_slots=2)      # 2 slots: exercises back-pressure
             assert os.path.getsize(os.path.join(disk.state_data_directory, "rollout.bin")) == \
-                40 + T * (N * 32 * 72 + N * 17) + T * N * 4          # header, T step records, returns column
+                40 + T * (N * state_bytes + N * 17) + T * N * 4      # header, T step records, returns column
             assert len(disk) == N * T
             ro = P.load_disk_rollouts(disk.state_data_directory, env)               # DiskDataset path
         st, act = ro.state_data
@@ -767,6 +839,37 @@ def test_streamed_disk_rollouts_roundtrip(P, orc, tmp_path):
                      ro.terminal, pol.params, ph, eh)
     for a, b in zip(res["memory"], res["disk"]):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_streamed_disk_rollouts_full_width(P, tmp_path):
+    """BASELINE config 5 width: 65536 envs streamed to disk (T small), bf16 policy.  The stream carries env snapshots
+    (81 B per env-step); the shard read back is the resident rollout column for column, and the observations re-derived
+    from it match the expanded form of a second, identical collection."""
+    N, T = 65536, 4
+    cols = {}
+    for mode in ("disk", "memory-expanded"):
+        env = P.HipVecEnv(num_envs=N, Q=8, max_actions=128, seed=3)
+        pol = P.HipPolicy(72, 256, 2, 4, seed=0, dtype="bf16")
+        if mode == "disk":
+            disk = P.DiskRollouts(str(tmp_path / "wide"))
+            P.collect_rollouts_steps_(disk, env, pol, T, 1.0)
+            sz = os.path.getsize(os.path.join(disk.state_data_directory, "rollout.bin"))
+            assert sz == 40 + T * N * (64 + 17) + T * N * 4
+            ro = P.load_disk_rollouts(disk.state_data_directory, env)
+        else:
+            P.set_rollout_compact(False)
+            try:
+                ro = P.BufferRollouts()
+                P.collect_rollouts_steps_(ro, env, pol, T, 1.0)
+            finally:
+                P.set_rollout_compact(None)
+        st, act = ro.state_data
+        cols[mode] = (st, act, ro.selected_actions, ro.selected_action_probabilities, ro.rewards, ro.terminal)
+        if mode == "disk":          # train straight from the reloaded snapshots (MODE 4 forward), one minibatch of 65536
+            h = P.ppo_train_(pol, P.Optimiser(P.Adam(1e-4)), P.construct_dataset(ro), 0.05, 65536, 1, 0.01, seed=0, verbose=False)
+            assert np.isfinite(h[0][0]) and np.isfinite(h[1][0])
+    for a, b in zip(cols["disk"], cols["memory-expanded"]):
+        assert np.array_equal(a, b)
 
 
 def test_ppo_iterate_disk_method(P, tmp_path):

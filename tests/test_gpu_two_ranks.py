@@ -104,7 +104,7 @@ def test_native_rccl_hook_single_rank(P):
     P.call("ppo_rccl_init", 0, 1, uid.ctypes.data_as(C.c_void_p))
 
     class Native:
-        world, force_hook = 1, True
+        rank, world, force_hook = 0, 1, True
 
         def make_hook(self, policy):
             return P._lib.ALLREDUCE_FN(C.cast(P._lib.lib().ppo_rccl_allreduce, C.c_void_p).value)

@@ -9,9 +9,10 @@ import ppo_amd as PPO
 N, T = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 env = PPO.HipVecEnv(num_envs=N, Q=8, max_actions=128, seed=3)
 pol = PPO.HipPolicy(72, 256, 2, 4, seed=0, dtype="bf16")
-res = {"envs": N, "steps": T, "bytes_per_step": N * (32 * 72 + 4 + 4 + 4 + 4 + 1 + 1)}
-for mode in ("resident", "streamed"):
+res = {"envs": N, "steps": T, "bytes_per_env_step": {"compact": 64 + 17, "expanded": 32 * 72 + 17}}
+for mode in ("resident", "streamed", "streamed_expanded"):
     d = tempfile.mkdtemp(prefix="ppo_stream_")
+    PPO.set_rollout_compact(False if mode == "streamed_expanded" else None)     # default: snapshots while streaming
     ro = PPO.BufferRollouts() if mode == "resident" else PPO.DiskRollouts(d)
     PPO.collect_rollouts_steps_(ro, env, pol, 2, 1.0)          # warm-up (allocations, first-touch)
     PPO.synchronize()
@@ -21,9 +22,10 @@ for mode in ("resident", "streamed"):
     PPO.synchronize()
     dt = time.perf_counter() - t0
     res[mode] = {"seconds": dt, "env_steps_per_s": N * T / dt}
-    if mode == "streamed":
+    if mode != "resident":
         sz = os.path.getsize(os.path.join(d, "rollout.bin"))
         res[mode]["file_bytes"] = sz
         res[mode]["GB_per_s_to_disk"] = sz / dt / 1e9
     shutil.rmtree(d, ignore_errors=True)
+res["streamed_over_resident"] = res["streamed"]["env_steps_per_s"] / res["resident"]["env_steps_per_s"]
 print(json.dumps(res))
