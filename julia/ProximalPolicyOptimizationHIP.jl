@@ -1,13 +1,16 @@
 # ProximalPolicyOptimizationHIP.jl -- reference-side binding of libppo_hip.so (include/ppo_hip.h).
 #
-# NOT EXECUTED in the build container (no `julia` binary; SURVEY.md 8(c)).  It is the binding a
-# maintainer of ProximalPolicyOptimization.jl would add: methods of the package's own generic
-# functions (src/ProximalPolicyOptimization.jl:16-30) for GPU-resident types, each a thin `ccall`.
-# Derived mechanically from include/ppo_hip.h; the Python mirror
-# (proximalpolicyoptimization.jl_amd/__init__.py) is the tested twin of this file.
+# UNTESTED AT RUN TIME: the build container has no `julia` binary (SURVEY.md 8(c)), so this file has never been
+# executed.  What IS checked, on every test run, is its C boundary: tests/test_abi.py parses every `ccall` below and
+# compares symbol, arity and argument types with include/ppo_hip.h.  It is the binding a maintainer of
+# ProximalPolicyOptimization.jl would add: methods of the package's own generic functions
+# (src/ProximalPolicyOptimization.jl:16-30) for GPU-resident types, each a thin `ccall`; the Python mirror
+# (proximalpolicyoptimization.jl_amd/__init__.py) is the executed twin of this file.
 module ProximalPolicyOptimizationHIP
 
 using ProximalPolicyOptimization
+import Flux
+using Printf
 const PPO = ProximalPolicyOptimization
 const LIB = get(ENV, "PPO_HIP_LIB", "libppo_hip.so")
 
@@ -19,14 +22,22 @@ function check(status::Int32)
     startswith(msg, "AssertionError") ? throw(AssertionError(msg)) : error(msg)
 end
 
+# Seed of the device-side minibatch permutations (the stand-in for randperm, src/train.jl:93).  The reference never
+# seeds its RNG; here runs are reproducible by default and `set_seed!` changes the stream.  The optimiser handle
+# counts the epochs it has trained, so successive ppo_train! calls draw different permutations from one seed.
+const SEED = Ref{UInt64}(0)
+set_seed!(s::Integer) = (SEED[] = UInt64(s))
+
 # ---------------------------------------------------------------- handles
 mutable struct HipVecEnv
-    h::Ptr{Cvoid}; N::Int; Q::Int; H::Int; F::Int; A::Int
+    h::Ptr{Cvoid}; N::Int; Q::Int; H::Int; F::Int; A::Int; max_actions::Int
     function HipVecEnv(num_envs; Q = 8, max_actions = 128, no_action_reward = -4f0, seed = 1234, global_offset = 0)
         r = Ref{Ptr{Cvoid}}()
         check(ccall((:ppo_env_create, LIB), Int32, (Int32, Int64, Int64, Int32, Int32, Float32, UInt64, Ref{Ptr{Cvoid}}),
                     0, num_envs, global_offset, Q, max_actions, no_action_reward, seed, r))
-        e = new(r[], num_envs, Q, 4Q, 72, 16Q)
+        n, hh, ff, aa = Ref{Int64}(), Ref{Int32}(), Ref{Int32}(), Ref{Int32}()          # shapes as the engine reports them
+        check(ccall((:ppo_env_dims, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int32}, Ref{Int32}, Ref{Int32}), r[], n, hh, ff, aa))
+        e = new(r[], n[], Q, hh[], ff[], aa[], max_actions)
         finalizer(x -> ccall((:ppo_env_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), e)
     end
 end
@@ -103,7 +114,7 @@ PPO.step!(env::HipVecEnv, actions::AbstractVector{<:Integer}) =                 
 
 # ---------------------------------------------------------------- policy / batching plugin methods  (:23-29)
 function PPO.batch_action_probabilities(p::HipPolicy, s::StateData)      # -> [A,B]
-    F, H, B = size(s.vertex_score, 1), size(s.vertex_score, 2), size(s.vertex_score, 3)
+    H, B = size(s.vertex_score, 2), size(s.vertex_score, 3)
     probs = Matrix{Float32}(undef, 4H, B)
     check(ccall((:ppo_policy_forward, LIB), Int32, (Ptr{Cvoid}, Ptr{Int8}, Ptr{UInt32}, Int64, Int32, Ptr{Float32}),
                 p.h, s.vertex_score, UInt32.(s.action_mask), B, H, probs))
@@ -114,36 +125,59 @@ PPO.number_of_actions_per_state(s::StateData) = 4 * size(s.vertex_score, 2)
 PPO.batch_advantage(s::StateData, returns) = returns                    # raw returns (no method exists upstream)
 
 # ---------------------------------------------------------------- path entry points
-function PPO.compute_returns(rewards::Vector{Float32}, terminal::AbstractVector{Bool}, discount, ::Val{:hip})
+# compute_returns(rewards, terminal, discount) (src/collect_rollouts.jl:26-42) on the device.  Its own name on purpose:
+# the reference's method is untyped, so a `PPO.compute_returns(::Vector{Float32}, ::Vector{Bool}, ::Any)` method here
+# would silently re-route every caller's CPU buffers; a user who wants exactly that adds the one-line method
+#     PPO.compute_returns(r::Vector{Float32}, t::Vector{Bool}, d) = ProximalPolicyOptimizationHIP.compute_returns_hip(r, t, d)
+function compute_returns_hip(rewards::Vector{Float32}, terminal::AbstractVector{Bool}, discount)
     out = similar(rewards)
     check(ccall((:ppo_compute_returns, LIB), Int32, (Ptr{Float32}, Ptr{UInt8}, Int64, Float64, Int32, Ptr{Float32}),
                 rewards, UInt8.(terminal), length(rewards), Float64(discount), discount isa Float32, out)); out
 end
 
+# collect_rollouts!(rollouts, env, policy, num_episodes, discount) (src/rollout_buffer.jl:66-79): exactly num_episodes
+# whole episodes, played in parallel on the resident envs (episode e on env e mod N)
 function PPO.collect_rollouts!(r::HipRollouts, env::HipVecEnv, p::HipPolicy, num_episodes, discount)
-    per_env = cld(num_episodes, env.N)
-    h = ensure!(r, env, per_env * 128)
+    h = ensure!(r, env, cld(num_episodes, env.N) * env.max_actions)
     check(ccall((:ppo_collect_rollouts_episodes, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Float64, Int32),
-                h, env.h, p.h, per_env, Float64(discount), discount isa Float32))
+                h, env.h, p.h, num_episodes, Float64(discount), discount isa Float32))
 end
 function Base.length(r::HipRollouts)
     n = Ref{Int64}(); check(ccall((:ppo_rollouts_len, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), r.h, n)); n[]
 end
 PPO.construct_dataset(r::HipRollouts) = r              # dataset == non-owning view of the same handle
 
-# batch_advantage plugin mode handed to the engine: 0 = returns (PPO.batch_advantage above), 1 = normalised returns
-const ADV_MODE = Ref{Int32}(0)
+# average_returns(policy, env, num_trajectories) (src/evaluate.jl:18-25) -> (mean, std)
+function PPO.average_returns(p::HipPolicy, env::HipVecEnv, num_trajectories)
+    scratch = HipRollouts()
+    h = ensure!(scratch, env, cld(num_trajectories, env.N) * env.max_actions)
+    m, s = Ref{Float64}(), Ref{Float64}()
+    check(ccall((:ppo_average_returns, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Float64}),
+                p.h, env.h, h, num_trajectories, m, s))
+    m[], s[]
+end
 
-function PPO.ppo_train!(p::HipPolicy, optimizer, r::HipRollouts, epsilon, batch_size, num_epochs, entropy_weight)
+# batch_advantage plugin mode handed to the engine: 0 = returns (PPO.batch_advantage above), 1 = normalised returns,
+# 2 / 3 = GAE(gamma, lambda) / normalised GAE over values supplied through compute_gae!
+const ADV_MODE = Ref{Int32}(0)
+function compute_gae!(r::HipRollouts, values::Matrix{Float32}, gamma, lambda)           # values: [N, T+1] column-major == [T+1][N]
+    check(ccall((:ppo_rollouts_compute_gae, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}, Float64, Float64, Ptr{Float32}, Ptr{Float32}),
+                r.h, values, Float64(gamma), Float64(lambda), C_NULL, C_NULL))
+end
+
+# ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight) (src/train.jl:130-153).
+# rank / world / hook: data-parallel runs (one process per GPU; INTEGRATION.md section 5); single process: 0 / 1 / C_NULL
+function PPO.ppo_train!(p::HipPolicy, optimizer, r::HipRollouts, epsilon, batch_size, num_epochs, entropy_weight;
+                        rank = 0, world = 1, hook = C_NULL)
     adam = first(optimizer)::HipAdam
     ph, eh, lh = zeros(num_epochs), zeros(num_epochs), zeros(num_epochs)
     check(ccall((:ppo_train, LIB), Int32,
-                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int32, Float64, Int32, Ptr{Int64}, UInt64, Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Int64, Int32, Float64, Int32, Ptr{Int64}, UInt64, Int32, Int32,
                  Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-                p.h, adam.h, r.h, epsilon, batch_size, num_epochs, entropy_weight, ADV_MODE[], C_NULL, rand(UInt64), 1,
-                C_NULL, C_NULL, ph, eh, lh))
+                p.h, adam.h, r.h, epsilon, batch_size, num_epochs, entropy_weight, ADV_MODE[], C_NULL, SEED[], rank, world,
+                hook, C_NULL, ph, eh, lh))
     for e in 1:num_epochs
-        PPO.@printf "EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e\n" e ph[e] eh[e] lh[e]
+        @printf "EPOCH : %d \t PPO LOSS : %1.4f\t ENTROPY LOSS : %1.4f \t LR : %1.1e\n" e ph[e] eh[e] lh[e]
     end
     ph, eh, lh
 end

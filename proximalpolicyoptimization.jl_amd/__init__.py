@@ -642,7 +642,7 @@ def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     call("ppo_collect_rollouts_episodes", h, env._h, policy._h, int(num_episodes), g, f32)
 
 
-def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=4):
+def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=8):
     """Vectorised fixed-T form: num_steps steps of all N envs with auto-reset (the throughput path).
     With a DiskRollouts target every finished step is streamed device -> pinned host -> <dir>/rollout.bin
     while the next step runs (ppo_rollouts_attach_disk)."""

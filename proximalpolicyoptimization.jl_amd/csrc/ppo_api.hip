@@ -538,16 +538,26 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     if (record_probs) PPO_TRY(ro->full_probs.alloc((size_t)T * N * env->A));
     // an env left terminal by a previous call starts a fresh episode (reset! before each episode)
     PPO_TRY(launch_env_reset(env, 1));
-    // One launch for the whole rollout (every wave walks its envs through all T steps: k_policy_fwd MODE 3) when nothing
-    // has to happen between the steps (no per-step disk streaming).  Default: on for Q = 8, where the env update is
-    // wavefront-parallel (312.7 vs 314.6 ms per bench iteration, same box); off for Q = 32, whose update still runs on
-    // one lane.  ppo_set_rollout_persistent / PPO_ROLLOUT_PERSISTENT=0|1 override.
+    // One launch for the whole rollout (every wave walks its envs through all T steps: k_policy_fwd MODE 3).  Default: on
+    // for Q = 8, where the env update is wavefront-parallel (312.7 vs 314.6 ms per bench iteration, same box); off for
+    // Q = 32, whose update still runs on one lane.  ppo_set_rollout_persistent / PPO_ROLLOUT_PERSISTENT=0|1 override.
+    // With a disk sink attached the rollout is a CHAIN of such launches, a few steps each: the finished steps of launch k
+    // are copied device -> pinned host on the copy stream while launch k + 1 runs.
     const bool persistent_ok = g_rollout_persistent == 1 || (g_rollout_persistent < 0 && env->Q == 8);
     int32_t ps = PPO_ERR_UNSUPPORTED;
+    PPO_TRY(disk_sink_begin(ro, T));
     if (persistent_ok && !ro->sink) ps = launch_policy_rollout_persistent(pol, env, ro, T, record_probs);
+    else if (persistent_ok) {
+        const int64_t chunk = std::max(1, disk_sink_slots(ro) / 2);        // half the ring in flight, half draining
+        for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+            const int64_t tc = std::min(chunk, T - t0);
+            ps = launch_policy_rollout_persistent(pol, env, ro, tc, record_probs, t0);
+            if (ps != PPO_OK) break;                                       // t0 == 0: shape not covered -> per-step launches
+            for (int64_t t = t0; t < t0 + tc; ++t) PPO_TRY(disk_sink_step(ro, t));
+        }
+    }
     if (ps != PPO_OK && ps != PPO_ERR_UNSUPPORTED) return ps;
     if (ps == PPO_ERR_UNSUPPORTED) {
-    PPO_TRY(disk_sink_begin(ro, T));
     for (int64_t t = 0; t < T; ++t) {
         int8_t* st = compact ? env->obs_tmp.p : ro->states.p + (size_t)t * srow;
         uint32_t* am = ro->active.p + (size_t)t * N;
@@ -734,7 +744,8 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
     const size_t NT = p->HID / 32;
     PPO_TRY(p->act1.alloc((size_t)B * NT * 1024)); PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
     PPO_TRY(p->dY.alloc((size_t)B * 128)); PPO_TRY(p->loss_terms.alloc((size_t)B * 2));
-    PPO_TRY(p->slabs.alloc((size_t)256 * slab_floats(p->F, p->HID)));
+    // one gradient slab per backward workgroup: 256, or 512 where two workgroups share a CU (fp32 HID = 128, F = 72)
+    PPO_TRY(p->slabs.alloc((size_t)((p->HID == 128 && p->F == 72) ? 512 : 256) * slab_floats(p->F, p->HID)));
     PPO_TRY(p->idx.alloc((size_t)B));
     p->cap_tiles = B;
     return PPO_OK;

@@ -37,6 +37,28 @@ struct DiskSink {
     bool stop = false, failed = false;
 };
 
+// Process-wide pool of pinned records: the reference creates a fresh DiskRollouts every PPO iteration
+// (src/train.jl:185), and hipHostMalloc / hipHostFree of the ring cost more than streaming a short rollout.
+static std::mutex g_pool_mu;
+static std::vector<std::pair<size_t, char*>> g_pinned_pool;
+static char* pinned_get(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pinned_pool.size(); ++i)
+            if (g_pinned_pool[i].first == bytes) { char* p = g_pinned_pool[i].second; g_pinned_pool.erase(g_pinned_pool.begin() + i); return p; }
+    }
+    char* p = nullptr;
+    return hipHostMalloc((void**)&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+static void pinned_put(size_t bytes, char* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t held = 0;
+    for (auto& e : g_pinned_pool) held += e.first;
+    if (held + bytes > ((size_t)2 << 30)) { (void)hipHostFree(p); return; }      // keep at most 2 GiB pinned
+    g_pinned_pool.emplace_back(bytes, p);
+}
+
 static int rm_rf(const std::string& path) {
     struct stat st;
     if (lstat(path.c_str(), &st) != 0) return 0;
@@ -81,7 +103,7 @@ void disk_sink_destroy(DiskSink* s) {
         s->writer.join();
     }
     if (s->f) fclose(s->f);
-    for (char* p : s->pinned) if (p) (void)hipHostFree(p);
+    for (char* p : s->pinned) pinned_put(s->rec_bytes, p);
     for (auto e : s->produced) (void)hipEventDestroy(e);
     for (auto e : s->copied) (void)hipEventDestroy(e);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
@@ -129,6 +151,8 @@ extern "C" int32_t ppo_rollouts_detach_disk(ppo_rollouts_t ro) {
     return PPO_OK;
 }
 
+int disk_sink_slots(const ppo_rollouts_s* ro) { return ro->sink ? ro->sink->slots : 0; }
+
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     DiskSink* s = ro->sink;
     if (!s) return PPO_OK;
@@ -141,10 +165,10 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     s->enq = s->written = 0; s->stop = false; s->failed = false;
     const size_t rec = record_bytes(ro, ro->compact);           // the storage form is decided per collection
     if (rec != s->rec_bytes) {
-        for (char*& p : s->pinned) { if (p) (void)hipHostFree(p); p = nullptr; }
-        for (int i = 0; i < s->slots; ++i)
-            if (hipHostMalloc((void**)&s->pinned[i], rec, hipHostMallocDefault) != hipSuccess) { ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP; }
+        for (char*& p : s->pinned) { pinned_put(s->rec_bytes, p); p = nullptr; }
         s->rec_bytes = rec;
+        for (int i = 0; i < s->slots; ++i)
+            if (!(s->pinned[i] = pinned_get(rec))) { ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP; }
     }
     const std::string path = s->dir + "/rollout.bin";
     s->f = fopen(path.c_str(), "wb");

@@ -149,6 +149,7 @@ extern "C" int32_t set_index_all(ppo_rollouts_s* r);
 
 // out-of-core store hooks used by ppo_collect_rollouts (ppo_disk.hip)
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T);
+int disk_sink_slots(const ppo_rollouts_s* ro);                // pinned records in the ring (0: no sink)
 int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t);       // after the kernels of step t were enqueued
 int32_t disk_sink_finish(ppo_rollouts_s* ro);                // after the return scan: appends returns, flushes
 void disk_sink_destroy(DiskSink* s);
@@ -182,7 +183,8 @@ int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uin
 int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
                               int32_t* actions_out, float* psel_out, float* full_probs_or_null);
 // adv_col: the advantage column indexed by transition id (ro->returns for PPO_ADV_RETURNS)
-int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs);
+int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs,
+                                         int64_t t0 = 0);
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                 int64_t B_global, double eps, double entropy_weight, const float* adv_col);
 int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col);

@@ -49,8 +49,20 @@ struct BwdArgs {
     float* slabs; size_t slab_stride;
 };
 
+// HID = 128, F = 72: a workgroup is 4 waves (one per SIMD) and nothing covers its barriers and VALU gradient sums --
+// unless a SECOND workgroup shares the CU.  Registers allow it (~220 per wave); LDS did not (86.5 KB).  So in this
+// shape X^T is staged as int8 (2.3 KB instead of 9.2 KB as floats; the B operands of phase D are converted on the way
+// in, 8 VALU per 16-byte read), which brings the workgroup to 79.6 KB: two per CU, 512 workgroups per launch.
 template <int F, int HID>
-__global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(BwdArgs a) {
+struct BwdCfg {
+    static constexpr bool XI8 = (HID == 128 && F == 72);
+    static constexpr int WG_PER_CU = XI8 ? 2 : 1;
+    static constexpr int MIN_WAVES = (HID >= 256 || XI8) ? 2 : 1;       // per SIMD (caps the register budget at 256)
+};
+
+template <int F, int HID>
+__global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy_bwd(BwdArgs a) {
+    constexpr bool XI8 = BwdCfg<F, HID>::XI8;
     constexpr int NT = HID / 32;                // feature tiles == waves per workgroup (wave w owns tile w)
     constexpr int NTHR = NT * 64;
     constexpr int FP = ((F + 31) / 32) * 32;
@@ -75,8 +87,9 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
     float* sH1 = sZ2 + HID * LD;                // [HID][33]  H1^T
     float* sH2 = sH1 + HID * LD;                // [HID][33]  H2^T
     float* sZ1 = sH2 + HID * LD;                // [HID][33]  dZ1^T
-    float* sX = sZ1 + HID * LD;                 // [NIM*32][33]  X^T (float), MFMA part
-    float* sXt = sX + NIM * 32 * LD;            // [32][FT]      X tail columns, row-major per tile row
+    float* sX = sZ1 + HID * LD;                 // [NIM*32][33]  X^T (float), MFMA part  (XI8: int8 [NIM*32][LD bytes])
+    int8_t* const sXb = reinterpret_cast<int8_t*>(sX);
+    float* sXt = XI8 ? sX + NIM * 32 * LD / 4 : sX + NIM * 32 * LD;   // [32][FT]      X tail columns, row-major per tile row
     float* sDY = sXt + 32 * (FT > 0 ? FT : 4);  // [32][4]
     float* sW3 = sDY + 32 * 4;                  // [HID][4]   W3[:,f] per feature (staged once)
 
@@ -220,8 +233,10 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xv = (float)(int)(int8_t)(xd[i] >> (8 * e));
-                    if (4 * c < NIM * 32) sX[(4 * c + e) * LD + row] = xv;
-                    else sXt[row * FT + (4 * c - NIM * 32) + e] = xv;
+                    if (4 * c < NIM * 32) {
+                        if (XI8) sXb[(4 * c + e) * LD + row] = (int8_t)(xd[i] >> (8 * e));
+                        else sX[(4 * c + e) * LD + row] = xv;
+                    } else sXt[row * FT + (4 * c - NIM * 32) + e] = xv;
                 }
             }
         }
@@ -402,7 +417,11 @@ __global__ __launch_bounds__(HID * 2, (HID >= 256 ? 2 : 1)) void k_policy_bwd(Bw
                 const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
 #pragma unroll
                 for (int it = 0; it < NIM; ++it) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
+                    float4 b4;
+                    if (XI8) {                                   // four rows of feature 32 it + j as one dword of int8
+                        const uint32_t d = *reinterpret_cast<const uint32_t*>(sXb + (32 * it + j) * LD + 16 * h + 4 * q);
+                        b4 = make_float4((float)(int)(int8_t)(d), (float)(int)(int8_t)(d >> 8), (float)(int)(int8_t)(d >> 16), (float)(int)(int8_t)(d >> 24));
+                    } else b4 = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
                     accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, accW1[it], 0, 0, 0);
                     accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, accW1[it], 0, 0, 0);
                     accW1[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, accW1[it], 0, 0, 0);
@@ -470,7 +489,8 @@ extern "C" int32_t ppo_debug_bwd_stamps(unsigned long long* out) {
 
 template <int F, int HID>
 static size_t bwd_lds_bytes() {
-    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + (size_t)(F / 32) * 32 * PPO_BWD_LD + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
+    const size_t xt = (size_t)(F / 32) * 32 * PPO_BWD_LD;      // X^T elements: floats, or bytes in the int8 form
+    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + (BwdCfg<F, HID>::XI8 ? xt / 4 : xt) + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
                             (size_t)HID * 4);
 }
 
@@ -487,11 +507,13 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
 #ifdef PPO_BWD_STAMP
     { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 20 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
 #endif
-    const int nwg = (int)(a.B < 256 ? a.B : 256);
-    p->nwg_bwd = nwg;
+    int nwg = 0;
     ProfScope ps("k_policy_bwd");
 #define LAUNCH(FF, HH)                                                                                        \
     do {                                                                                                      \
+        const int64_t cap = 256 * BwdCfg<FF, HH>::WG_PER_CU;                                                  \
+        nwg = (int)(a.B < cap ? a.B : cap);                                                                   \
+        p->nwg_bwd = nwg;                                                                                     \
         const size_t lds = bwd_lds_bytes<FF, HH>();                                                           \
         static bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \

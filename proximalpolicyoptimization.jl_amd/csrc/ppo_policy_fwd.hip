@@ -466,7 +466,9 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 
 // Persistent rollout (MODE 3): T steps of all N envs in one launch.  Returns PPO_ERR_UNSUPPORTED (without setting an
 // error) when the shape is not covered, so the caller falls back to the per-step launches.
-int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs) {
+// t0: first row of the rollout columns this launch writes (streaming collects a long rollout as a chain of launches)
+int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs,
+                                         int64_t t0) {
     if (p->F != 72 || e->F != 72) return PPO_ERR_UNSUPPORTED;
     const int tps = e->H / 32;
     const int64_t N = e->N;
@@ -485,10 +487,12 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     a.env_reward = e->reward.p; a.env_done = e->done.p; a.env_episode = e->episode.p; a.env_tick = e->tick.p;
     a.env_tmpl = e->tmpl.p; a.envQ = e->Q; a.envV = e->V; a.env_max_actions = e->max_actions; a.env_slots = slots;
     a.env_nar = e->no_action_reward; a.err = e->err.p;
-    a.states_out = ro->compact ? nullptr : ro->states.p; a.cstate_out = ro->compact ? ro->cstate.p : nullptr;
-    a.active_out = ro->active.p; a.actions_out = ro->actions.p; a.psel_out = ro->p_sel.p;
-    a.rew_out = ro->rewards.p; a.done_out = ro->done.p;
-    a.full_probs = record_probs ? ro->full_probs.p : nullptr;
+    const size_t r0 = (size_t)t0 * N;                                   // transitions in front of this launch's rows
+    a.states_out = ro->compact ? nullptr : ro->states.p + r0 * e->H * e->F;
+    a.cstate_out = ro->compact ? ro->cstate.p + r0 * 2 * e->V : nullptr;
+    a.active_out = ro->active.p + r0; a.actions_out = ro->actions.p + r0; a.psel_out = ro->p_sel.p + r0;
+    a.rew_out = ro->rewards.p + r0; a.done_out = ro->done.p + r0;
+    a.full_probs = record_probs ? ro->full_probs.p + r0 * e->A : nullptr;
     ProfScope ps("k_rollout_persistent");
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_rollout_persistent_bf16(p, a, N, tps, e->V);
 #define LAUNCH3(HH, TT)                                                                                      \

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ppo_amd as PPO
 
-N, T = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+N, T = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 128
 env = PPO.HipVecEnv(num_envs=N, Q=8, max_actions=128, seed=3)
 pol = PPO.HipPolicy(72, 256, 2, 4, seed=0, dtype="bf16")
 res = {"envs": N, "steps": T, "bytes_per_env_step": {"compact": 64 + 17, "expanded": 32 * 72 + 17}}
