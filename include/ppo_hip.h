@@ -209,6 +209,11 @@ int32_t ppo_rollouts_set(ppo_rollouts_t ro, int64_t T, const int8_t* states, con
 int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t* sample_idx,
                              int64_t B, int64_t B_global, double epsilon, double entropy_weight,
                              int32_t adv_mode);
+/* Which backward kernel a minibatch takes (same gradient, different reduction tree: results agree to fp32 rounding):
+ * up to `tiles` 32-row tiles the three-product form (dZ kernel + output-stationary split-K weight-gradient kernel: no
+ * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
+ * keeps every weight gradient resident in MFMA accumulators.  Default 1536 (-1 restores it), 0 = always fused. */
+int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
 /* Flux.update!(optimizer, weights, grad)                    src/train.jl:81 */
 int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol);
 /* losses of the last forward_backward (after any all-reduce): (ppoloss, entropy_weight*entropyloss)

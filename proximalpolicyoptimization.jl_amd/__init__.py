@@ -104,6 +104,12 @@ def set_rollout_compact(on=None):
     call("ppo_set_rollout_compact", -1 if on is None else int(bool(on)))
 
 
+def set_bwd_small_max_tiles(tiles=None):
+    """Minibatches of up to `tiles` 32-row tiles use the three-product backward (no per-workgroup gradient slabs), larger
+    ones the fused kernel.  None = default (1536), 0 = always the fused kernel."""
+    call("ppo_set_bwd_small_max_tiles", -1 if tiles is None else int(tiles))
+
+
 def synchronize():
     call("ppo_device_synchronize")
 
@@ -642,7 +648,7 @@ def collect_rollouts_(rollouts, env, policy, num_episodes, discount):
     call("ppo_collect_rollouts_episodes", h, env._h, policy._h, int(num_episodes), g, f32)
 
 
-def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=8):
+def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_probs=False, pinned_slots=16):
     """Vectorised fixed-T form: num_steps steps of all N envs with auto-reset (the throughput path).
     With a DiskRollouts target every finished step is streamed device -> pinned host -> <dir>/rollout.bin
     while the next step runs (ppo_rollouts_attach_disk)."""

@@ -88,6 +88,7 @@ struct ppo_policy_s {
     DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
     // training workspace
     DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4
+    DevBuf<float> dz2f, dz1f;          // small-minibatch backward: dZ2 / dZ1 in fragment order (like act1 / act2)
     DevBuf<float> dY;                  // [tiles][32][4]
     DevBuf<double> loss_terms;         // [tiles][2]
     DevBuf<float> slabs;               // [nwg][slab]
@@ -96,7 +97,8 @@ struct ppo_policy_s {
     DevBuf<float> adv_col;             // batch_advantage scratch column [T*N] (PPO_ADV_RETURNS_NORMALISED)
     DevBuf<int32_t> err;               // device error flag
     int64_t cap_tiles = 0;
-    int32_t nwg_bwd = 0;
+    int32_t nwg_bwd = 0;               // slabs holding weight-gradient partials of the last backward
+    int32_t nwg_small = 0;             // slabs holding its small-gradient tails (0: the same slabs)
     int64_t last_B = 0;
     double last_entropy_weight = 0.0;
 };
@@ -189,6 +191,8 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
                                 int64_t B_global, double eps, double entropy_weight, const float* adv_col);
 int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col);
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+// three-product backward for small minibatches (ppo_policy_bwd_small.hip); PPO_ERR_UNSUPPORTED: not covered
+int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 // bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
 struct FwdArgs;
 int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t B, int tps);

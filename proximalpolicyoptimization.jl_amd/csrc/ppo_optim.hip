@@ -26,7 +26,8 @@ __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, d
 // Block = 64 consecutive slab elements x 4 slab groups (wave g sums slabs g, g+4, g+8, ... with 8 loads in flight);
 // the four partial sums meet in LDS and are added in a fixed order.  4x the waves of a one-thread-per-element
 // layout: the 87 MB slab walk needs the memory-level parallelism (341 blocks of one wave per SIMD did 3.3 TB/s).
-__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg, ParamLayout L,
+// nwg_w slabs carry weight-gradient partials, nwg_s slabs the small-gradient tails (equal for the fused backward)
+__global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg_w, int nwg_s, ParamLayout L,
                                                      float* __restrict__ grad, const double* __restrict__ terms, int64_t B,
                                                      double inv_Bg, double entropy_weight) {
     if (blockIdx.x == gridDim.x - 1) {          // the extra last block reduces the per-sample loss terms
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     // fixed summation order: 8 interleaved partial sums per slab group, a fixed tree, then the 4 groups in order
     float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nwg = (e < nW2 + nW1) ? nwg_w : nwg_s;
     if (e < total) {
         int g = grp;
         for (; g + 28 < nwg; g += 32) {
@@ -225,7 +227,7 @@ int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double 
     const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     ProfScope ps("k_grad_reduce");
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 63) / 64) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
-                       slab_floats(p->F, p->HID), p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
+                       slab_floats(p->F, p->HID), p->nwg_bwd, p->nwg_small ? p->nwg_small : p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
                        entropy_weight);
     HIP_TRY(hipGetLastError());
     return PPO_OK;

@@ -1001,7 +1001,7 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     a.stamps = g_bf16_stamps;
 #endif
     const int nwg = (int)(a.B < 256 ? a.B : 256);
-    p->nwg_bwd = nwg;
+    p->nwg_bwd = nwg; p->nwg_small = 0;
     a.nwg = nwg;
 #define LAUNCHB(FF, HH)                                                                                           \
     do {                                                                                                          \

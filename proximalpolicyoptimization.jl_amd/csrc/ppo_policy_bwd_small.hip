@@ -1,0 +1,366 @@
+// ppo_policy_bwd_small.hip -- K11 for SMALL minibatches (a few hundred 32-row tiles: the per-GPU shard of a strong-
+// scaling run, or the reference's own batch sizes): the same gradient as k_policy_bwd (Zygote's Flux.gradient of
+// step_batch!, src/train.jl:65-79; math: SURVEY.md Appendix A) organised as the classic three products instead of one
+// fused pass.
+//
+// Why: the fused kernel keeps a full weight-gradient accumulator set per workgroup and ends with one 341 KB slab per
+// workgroup -- 87 MB written and 87 MB re-read by k_grad_reduce whatever the batch size (17 + 17 us).  At 4096 tiles
+// that is 6 % of the optimiser step; at 512 tiles (two tiles per workgroup) it is 27 %.  Here the weight gradients are
+// output-stationary: every 64 x 64 block of dW2 / 64 x 96 block of dW1 has a few owners that split the ROWS between
+// them (split-K), so the partials are 18 MB at any batch size and nothing is accumulated that is not also reduced.
+//   k_policy_bwd_data   per tile: dZ2 = (W3^T dY) . lrelu'(H2), dH1 = W2^T dZ2 (MFMA), dZ1 = dH1 . lrelu'(H1), the
+//                       small gradients (db1, db2, dW3, db3); dZ2 / dZ1 leave in the forward's accumulator-fragment
+//                       order (coalesced 1 KiB stores), 67 MB at 512 tiles: L2 / Infinity-Cache resident
+//   k_policy_wgrad      dW2 += dZ2 H1^T, dW1 += dZ1 X^T: workgroup = (output block, K-slice), 4 waves interleave the row
+//                       tiles of the slice; operands come back with coalesced fragment loads and are transposed through
+//                       wave-private LDS ([feature][36], the layout of k_policy_bwd's phases C / D); every wave writes
+//                       its accumulators into the block's region of "virtual slab" (slice, wave)
+//   k_grad_reduce       unchanged: fixed-order sum of the virtual slabs -> flat Flux-order gradient (bitwise reproducible)
+#include "ppo_internal.h"
+#include "ppo_device.h"
+
+#define SB_LD 36        // LDS leading dimension (rows) of the transposed tiles: see k_policy_bwd
+
+struct BwdSmallArgs {
+    const int8_t* states; const int32_t* idx; int64_t B;   // B = 32-row tiles
+    int tps, x_by_tile;
+    const float4* act1; const float4* act2; const float4* dY;
+    const float4* w2tp; const float4* w3p;
+    float4* dz2f; float4* dz1f;                             // [tile][feature tile][4][64] float4, like act1 / act2
+    float* slabs; size_t slab_stride;
+    int ksplit;                                             // K-slices of k_policy_wgrad
+};
+
+// ---------------------------------------------------------------------------------------------- backward-data
+template <int F, int HID>
+__global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) {
+    constexpr int NT = HID / 32, LD = SB_LD, S4 = HID / 8, FP = ((F + 31) / 32) * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sZ2 = smem;                          // [HID][LD] dZ2^T
+    float* sH2 = sZ2 + HID * LD;                // [HID][LD] H2^T
+    float* sZ1 = sH2 + HID * LD;                // [HID][LD] dZ1^T
+    float* sDY = sZ1 + HID * LD;                // [32][4]
+    float* sW3 = sDY + 32 * 4;                  // [HID][4]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float db1 = 0.f, db2 = 0.f, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
+        const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
+    }
+    __syncthreads();
+    const float4* const w2t = a.w2tp + (size_t)w * S4 * 64 + lane;     // this wave's W2^T tile
+    const unsigned fb = (unsigned)(32 * w + 4 * h);
+    for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        unsigned lb = fb * LD + j;
+        asm volatile("" : "+v"(lb));                                   // per-tile opaque base (see k_policy_bwd)
+        float* const z2b = sZ2 + lb;
+        float* const h2b = sH2 + lb;
+        float* const z1b = sZ1 + lb;
+        const float* const w3b = sW3 + fb * 4;
+        // ---- phase A: dZ2 of feature tile w
+        float4 v1[4], v2[4];
+        const float4* s1 = a.act1 + ((size_t)tile * NT + w) * 4 * 64 + lane;
+        const float4* s2 = a.act2 + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v2[q] = s2[q * 64]; v1[q] = s1[q * 64]; }
+        const float4 dy = a.dY[(size_t)tile * 32 + j];
+        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        float4* const zo = a.dz2f + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
+            float z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = e + 8 * q;
+                const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
+                const float dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
+                z[e] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                z2b[fo * LD] = z[e];
+                h2b[fo * LD] = h2v[e];
+            }
+            zo[q * 64] = make_float4(z[0], z[1], z[2], z[3]);
+        }
+        __syncthreads();
+        // ---- phase B: small grads of feature 32w + j (rows 16h .. 16h+15), dH1 tile w = W2^T dZ2, dZ1
+        {
+            const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
+            const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
+            const float* gy = sDY + 64 * h;
+            float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 1
+            for (int rc = 0; rc < 16; rc += 4) {
+                const float4 z4 = *reinterpret_cast<const float4*>(gz + rc);
+                const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
+                const float z[4] = {z4.x, z4.y, z4.z, z4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 y = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
+                    s2 += z[i]; d0 = fmaf(y.x, hv[i], d0); d1 = fmaf(y.y, hv[i], d1); d2 = fmaf(y.z, hv[i], d2); d3 = fmaf(y.w, hv[i], d3);
+                }
+            }
+            db2 += s2; dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
+            if (tid < 4) {
+                float s = 0.f;
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                db3 += s;
+            }
+        }
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
+            constexpr int PF = 4;
+            float4 ring[PF];
+#pragma unroll
+            for (int g = 0; g < PF; ++g) ring[g] = w2t[(size_t)g * 64];
+#pragma unroll 2
+            for (int s0 = 0; s0 < S4; s0 += PF) {
+                float4 cur[PF];
+#pragma unroll
+                for (int g = 0; g < PF; ++g) { cur[g] = ring[g]; ring[g] = w2t[(size_t)(s0 + PF + g) * 64]; }   // tail padding covers the over-read
+#pragma unroll
+                for (int g = 0; g < PF; ++g) {
+                    float b[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * (s0 + g) + 2 * e) * LD];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].x, b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].y, b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].z, b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].w, b[3], acc, 0, 0, 0);
+                }
+            }
+            float4* const z1o = a.dz1f + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h1v[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    z[e] = acc[4 * q + e] * (h1v[e] > 0.0f ? 1.0f : 0.01f);
+                    z1b[(e + 8 * q) * LD] = z[e];
+                }
+                z1o[q * 64] = make_float4(z[0], z[1], z[2], z[3]);
+            }
+        }
+        __syncthreads();
+        // ---- db1 of feature 32w + j
+        {
+            const float* g1 = sZ1 + (32 * w + j) * LD + 16 * h;
+            float s1 = 0.f;
+#pragma unroll
+            for (int rc = 0; rc < 16; rc += 4) {
+                const float4 z4 = *reinterpret_cast<const float4*>(g1 + rc);
+                s1 += z4.x; s1 += z4.y; s1 += z4.z; s1 += z4.w;
+            }
+            db1 += s1;
+        }
+        // no barrier here: the next tile's phase A writes sZ2 / sH2 / sDY only, which every wave finished reading before
+        // the barrier above; sZ1 is rewritten behind the next tile's first barrier
+    }
+    // small-gradient tail of slab blockIdx.x (same places as k_policy_bwd's slab)
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride + (size_t)HID * HID + (size_t)HID * FP;
+    float* sb1 = slab; float* sb2 = sb1 + HID; float* sw3 = sb2 + HID; float* sb3 = sw3 + HID * 4;
+    db1 += __shfl_xor(db1, 32); db2 += __shfl_xor(db2, 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dw3[i] += __shfl_xor(dw3[i], 32);
+    if (h == 0) {
+        const int f = 32 * w + j;
+        sb1[f] = db1; sb2[f] = db2;
+        *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(dw3[0], dw3[1], dw3[2], dw3[3]);
+    }
+    if (tid < 4) sb3[tid] = db3;
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradients
+// wave-private transposed tile: fragment (lane = row, registers = 16 features) -> [feature][LD rows]
+__device__ __forceinline__ void frag_to_lds(float* buf, const float4 (&v)[4], int j, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) buf[(4 * h + e + 8 * q) * SB_LD + j] = x[e];
+    }
+}
+
+template <int F, int HID>
+__global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
+    constexpr int NT = HID / 32, LD = SB_LD, FP = ((F + 31) / 32) * 32, NI = FP / 32;
+    constexpr int NB2 = (NT / 2) * (NT / 2);            // 64 x 64 blocks of dW2 (2 A tiles + 2 B tiles)
+    constexpr int NB1 = NT;                             // 32 x FP blocks of dW1 (1 A tile + NI B tiles)
+    constexpr int TILE = 32 * LD;                       // floats of one transposed tile
+    constexpr int WT = (1 + NI > 4) ? 1 + NI : 4;       // transposed tiles per wave (4 -> 73.7 KB per workgroup: two per CU)
+    constexpr int XDW = 32 * F / 4, XPL = (XDW + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* const bufA = smem + (size_t)v * WT * TILE;                  // wave-private: A tiles first, then the B tiles
+    const int block = blockIdx.x % (NB2 + NB1), slice = blockIdx.x / (NB2 + NB1);
+    const int64_t per = (a.B + a.ksplit - 1) / a.ksplit;
+    const int64_t t0 = (int64_t)slice * per, t1 = (t0 + per < a.B) ? t0 + per : a.B;
+    float* slab = a.slabs + (size_t)(slice * 4 + v) * a.slab_stride;
+    float* sW2 = slab;
+    float* sW1 = slab + (size_t)HID * HID;
+    if (block < NB2) {
+        // ---------------- dW2 block: f-tiles 2fb, 2fb+1 x k-tiles 2kb, 2kb+1
+        const int fbk = block / (NT / 2), kbk = block % (NT / 2);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+        float* const bufB = bufA + 2 * TILE;
+        float4 fa[2][4], fbv[2][4];
+        auto fetch = [&](int64_t t) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fa[x][q] = a.dz2f[((size_t)t * NT + (2 * fbk + x)) * 4 * 64 + q * 64 + lane];
+                    fbv[x][q] = a.act1[((size_t)t * NT + (2 * kbk + x)) * 4 * 64 + q * 64 + lane];
+                }
+        };
+        if (t0 + v < t1) fetch(t0 + v);
+        for (int64_t t = t0 + v; t < t1; t += 4) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) { frag_to_lds(bufA + x * TILE, fa[x], j, h); frag_to_lds(bufB + x * TILE, fbv[x], j, h); }
+            if (t + 4 < t1) fetch(t + 4);                              // next row tile lands under the MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private tiles: own writes have landed
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                float4 a4[2], b4[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    a4[x] = *reinterpret_cast<const float4*>(bufA + x * TILE + j * LD + 16 * h + 4 * q);
+                    b4[x] = *reinterpret_cast<const float4*>(bufB + x * TILE + j * LD + 16 * h + 4 * q);
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[x].x, b4[y].x, acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[x].y, b4[y].y, acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[x].z, b4[y].z, acc[x][y], 0, 0, 0);
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[x].w, b4[y].w, acc[x][y], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next tile overwrites the buffers
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sW2[((size_t)((2 * fbk + x) * NT + (2 * kbk + y)) * 16 + r) * 64 + lane] = acc[x][y][r];
+    } else {
+        // ---------------- dW1 block: k-tile kb x all NI input tiles (columns >= F are zero padding)
+        const int kbk = block - NB2;
+        float* const bufB = bufA + TILE;
+        f32x16 acc[NI];
+#pragma unroll
+        for (int y = 0; y < NI; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][r] = 0.0f;
+        for (int i = lane; i < NI * TILE; i += 64) bufB[i] = 0.0f;    // padded input features stay zero
+        float4 fa[4];
+        uint32_t xd[XPL];
+        auto fetch = [&](int64_t t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = a.dz1f[((size_t)t * NT + kbk) * 4 * 64 + q * 64 + lane];
+            const int sidx = a.x_by_tile ? 0 : a.idx[t / a.tps];
+            const uint32_t* xs = reinterpret_cast<const uint32_t*>(
+                a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
+#pragma unroll
+            for (int i = 0; i < XPL; ++i) { const int d = lane + 64 * i; xd[i] = d < XDW ? xs[d] : 0u; }
+        };
+        if (t0 + v < t1) fetch(t0 + v);
+        for (int64_t t = t0 + v; t < t1; t += 4) {
+            frag_to_lds(bufA, fa, j, h);
+#pragma unroll
+            for (int i = 0; i < XPL; ++i) {
+                const int d = lane + 64 * i;                          // dword d = row * (F/4) + c: features 4c .. 4c+3
+                if (d < XDW) {
+                    const int row = d / (F / 4), c = d % (F / 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bufB[(4 * c + e) * LD + row] = (float)(int)(int8_t)(xd[i] >> (8 * e));
+                }
+            }
+            if (t + 4 < t1) fetch(t + 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(bufA + j * LD + 16 * h + 4 * q);
+                float4 b4[NI];
+#pragma unroll
+                for (int y = 0; y < NI; ++y) b4[y] = *reinterpret_cast<const float4*>(bufB + y * TILE + j * LD + 16 * h + 4 * q);
+#pragma unroll
+                for (int y = 0; y < NI; ++y) {
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[y].x, acc[y], 0, 0, 0);
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[y].y, acc[y], 0, 0, 0);
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[y].z, acc[y], 0, 0, 0);
+                    acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[y].w, acc[y], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int y = 0; y < NI; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sW1[((size_t)(kbk * NI + y) * 16 + r) * 64 + lane] = acc[y][r];
+    }
+}
+
+template <int F, int HID>
+static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
+    constexpr int NT = HID / 32, NI = (F + 31) / 32, WT = (1 + NI > 4) ? 1 + NI : 4;
+    const size_t lds_data = sizeof(float) * ((size_t)3 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
+    const size_t lds_w = sizeof(float) * (size_t)4 * WT * 32 * SB_LD;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_data));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_wgrad<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        attr_set = true;
+    }
+    const int nwg = (int)(a.B < 256 ? a.B : 256);
+    constexpr int blocks = (NT / 2) * (NT / 2) + NT;
+    // K-slices: two workgroups per CU over the block list, but never more virtual slabs (4 per slice) than the buffer holds
+    int ks = (512 + blocks - 1) / blocks;
+    if (ks * 4 > 256) ks = 64;
+    if ((int64_t)ks > a.B) ks = (int)a.B;
+    a.ksplit = ks;
+    p->nwg_bwd = ks * 4;             // slabs holding weight-gradient partials
+    p->nwg_small = nwg;              // slabs holding the small-gradient tails
+    {
+        ProfScope ps("k_policy_bwd_data");
+        hipLaunchKernelGGL((k_policy_bwd_data<F, HID>), dim3(nwg), dim3(HID * 2), lds_data, ppo_stream(), a);
+    }
+    {
+        ProfScope ps("k_policy_wgrad");
+        hipLaunchKernelGGL((k_policy_wgrad<F, HID>), dim3(blocks * ks), dim3(256), lds_w, ppo_stream(), a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
+// PPO_ERR_UNSUPPORTED (no error text): shape or size not covered -> the caller runs the fused kernel
+int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
+    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || !p->dz2f.p || !p->dz1f.p) return PPO_ERR_UNSUPPORTED;
+    BwdSmallArgs a;
+    a.tps = ro->H / 32;
+    a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
+    a.idx = idx_dev; a.B = B * a.tps;
+    a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
+    a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
+    a.dz2f = (float4*)p->dz2f.p; a.dz1f = (float4*)p->dz1f.p;
+    a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    a.ksplit = 1;
+    if (p->HID == 256) return launch_small<72, 256>(p, a);
+    if (p->HID == 128) return launch_small<72, 128>(p, a);
+    return PPO_ERR_UNSUPPORTED;
+}

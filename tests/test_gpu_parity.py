@@ -300,6 +300,15 @@ def storage_mode(request, P):
     P.set_rollout_compact(None)
 
 
+@pytest.fixture(params=[0, None], ids=["fused-bwd", "small-bwd"])
+def bwd_form(request, P):
+    """Both backward organisations at test sizes: the fused kernel (forced) and the three-product form small
+    minibatches take by default (ppo_set_bwd_small_max_tiles)."""
+    P.set_bwd_small_max_tiles(request.param)
+    yield request.param
+    P.set_bwd_small_max_tiles(None)
+
+
 @pytest.mark.parametrize("case", range(10))
 def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode, storage_mode):
     """Randomised shapes / seeds / horizons / global offsets: whole rollouts stay bit-identical to the device-order
@@ -332,7 +341,7 @@ def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode, storage_mode):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 31, 33, 255, 257])
-def test_gradient_ragged_batch_sizes(P, orc, B, storage_mode):
+def test_gradient_ragged_batch_sizes(P, orc, B, storage_mode, bwd_form):
     """Minibatches that do not fill the persistent grid (B = 1 ... 257 tiles on 256 workgroups) and repeat samples."""
     env, pol, ro, ds = _make_dataset(P, orc, 30, 10, 256, seed=77)      # 300 samples
     rng = np.random.default_rng(B)
@@ -438,7 +447,7 @@ def _oracle_grad(orc, pol_params, HID, ro, sel0, eps, ew):
 
 
 @pytest.mark.parametrize("HID,B", [(128, 24), (128, 300), (256, 40), (256, 520)])
-def test_gradient_vs_f64_oracle(P, orc, HID, B, storage_mode):
+def test_gradient_vs_f64_oracle(P, orc, HID, B, storage_mode, bwd_form):
     N, T = 40, 16
     env, pol, ro, ds = _make_dataset(P, orc, N, T, HID, seed=B)
     rng = np.random.default_rng(B)
@@ -457,7 +466,7 @@ def test_gradient_vs_f64_oracle(P, orc, HID, B, storage_mode):
 
 
 @pytest.mark.parametrize("fixture", ["poly-30-policy", "catmull-clark-policy"])
-def test_gradient_with_reference_trained_weights(P, orc, golden_dir, fixture):
+def test_gradient_with_reference_trained_weights(P, orc, golden_dir, fixture, bwd_form):
     """Zygote's gradient (src/train.jl:65-79) restated in float64, on the weights the REFERENCE trained
     (test/output/*.bson decoded into tests/golden/*.npz): rollout with those weights on the engine, then loss and
     gradient of a minibatch against orc_step_batch_grad_f64 -- same tolerance as for random-init weights."""
@@ -652,7 +661,7 @@ def test_policy_forward_q32(P, orc):
 
 
 @pytest.mark.parametrize("HID", [128, 256])
-def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode, storage_mode):
+def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode, storage_mode, bwd_form):
     """square_mesh-sized action space (Q=32 quads, 512 masked actions), variable-length episodes."""
     N, T, max_actions = 12, 20, 9
     env = P.HipVecEnv(num_envs=N, Q=32, max_actions=max_actions, seed=31)
