@@ -360,7 +360,7 @@ def main():
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
                                  "frac": round(tf / peak, 4)}
-        for name in ("k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
+        for name in ("k_policy_bwd_data", "k_policy_wgrad", "k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
                      "k_reduce_adam", "allreduce"):
             ms, n = PPO.profile_get(name)
             if n:

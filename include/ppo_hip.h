@@ -214,6 +214,10 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
  * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
  * keeps every weight gradient resident in MFMA accumulators.  Default 1536 (-1 restores it), 0 = always fused. */
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
+/* Likewise for the train forward: minibatches of up to `states` states (H = 32) give every state to 2 or 4 waves instead
+ * of one, so a minibatch smaller than the chip's 1024 SIMDs still fills it (logits agree with the one-wave kernel to
+ * fp32 rounding: the layer-3 partial sums are added in a different order).  Default 512 (-1 restores it), 0 = never. */
+int32_t ppo_set_fwd_split_max_states(int64_t states);
 /* Flux.update!(optimizer, weights, grad)                    src/train.jl:81 */
 int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol);
 /* losses of the last forward_backward (after any all-reduce): (ppoloss, entropy_weight*entropyloss)

@@ -110,6 +110,12 @@ def set_bwd_small_max_tiles(tiles=None):
     call("ppo_set_bwd_small_max_tiles", -1 if tiles is None else int(tiles))
 
 
+def set_fwd_split_max_states(states=None):
+    """Minibatches of up to `states` states use the train forward that gives each state to 2 or 4 waves.  None = default
+    (512), 0 = always one wave per state."""
+    call("ppo_set_fwd_split_max_states", -1 if states is None else int(states))
+
+
 def synchronize():
     call("ppo_device_synchronize")
 

@@ -18,6 +18,7 @@
 // dot-product epilogue.
 #include "ppo_policy_tail.h"
 #include "ppo_env_device.h"
+#include <cstdlib>
 
 // activation stores of the train forward: tuning knobs for A/B builds (defaults are the shipped configuration)
 #ifndef PPO_FWD_STORE
@@ -515,6 +516,10 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     return PPO_OK;
 }
 
+// minibatches of up to this many states take the split train forward; ppo_set_fwd_split_max_states / PPO_FWD_SPLIT_MAX_STATES
+static int64_t g_fwd_split_max_states = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_STATES"); return v ? (int64_t)atoll(v) : (int64_t)512; }();
+extern "C" int32_t ppo_set_fwd_split_max_states(int64_t states) { g_fwd_split_max_states = states < 0 ? 512 : states; return PPO_OK; }
+
 int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
                                 int64_t B_global, double eps, double entropy_weight, const float* adv_col) {
     FwdArgs a = {};
@@ -524,9 +529,15 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
     a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = adv_col;
     a.eps = eps; a.c_over_B = (float)(entropy_weight / (double)B_global); a.inv_B = (float)(1.0 / (double)B_global);
     ProfScope ps("k_policy_fwd_train");
-    if (ro->compact) {      // rows are re-derived from the env snapshots and left in p->xs (minibatch order) for the backward
+    if (ro->compact) {      // env snapshots instead of observation rows (MODE 4 / the CS form of the split kernel)
         a.states = nullptr; a.cstate = ro->cstate.p; a.xs_out = p->xs.p;
         a.env_tmpl = ro->tmpl.p; a.envV = ro->V; a.envQ = ro->V / 4; a.env_slots = 1;
+    }
+    if (B <= g_fwd_split_max_states) {        // small minibatch: 2 or 4 waves per state (ppo_policy_fwd_split.hip)
+        const int32_t rs = launch_policy_train_fwd_split(p, a, B, ro->H / 32, ro->compact);
+        if (rs != PPO_ERR_UNSUPPORTED) return rs;
+    }
+    if (ro->compact) {      // rows are re-derived from the env snapshots and left in p->xs (minibatch order) for the backward
         if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 4, B, ro->H / 32);
         return dispatch_fwd<4>(p, a, B, ro->H / 32);
     }

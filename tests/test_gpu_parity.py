@@ -300,13 +300,16 @@ def storage_mode(request, P):
     P.set_rollout_compact(None)
 
 
-@pytest.fixture(params=[0, None], ids=["fused-bwd", "small-bwd"])
+@pytest.fixture(params=[0, None], ids=["large-batch-kernels", "small-batch-kernels"])
 def bwd_form(request, P):
-    """Both backward organisations at test sizes: the fused kernel (forced) and the three-product form small
-    minibatches take by default (ppo_set_bwd_small_max_tiles)."""
+    """Both kernel sets at test sizes: the fused backward + one-wave-per-state train forward (forced), and what small
+    minibatches take by default: the three-product backward and the 2 / 4-waves-per-state train forward
+    (ppo_set_bwd_small_max_tiles, ppo_set_fwd_split_max_states)."""
     P.set_bwd_small_max_tiles(request.param)
+    P.set_fwd_split_max_states(request.param)
     yield request.param
     P.set_bwd_small_max_tiles(None)
+    P.set_fwd_split_max_states(None)
 
 
 @pytest.mark.parametrize("case", range(10))
