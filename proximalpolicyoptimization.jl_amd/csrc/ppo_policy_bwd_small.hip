@@ -7,14 +7,14 @@
 // workgroup -- 87 MB written and 87 MB re-read by k_grad_reduce whatever the batch size (17 + 17 us).  At 4096 tiles
 // that is 6 % of the optimiser step; at 512 tiles (two tiles per workgroup) it is 27 %.  Here the weight gradients are
 // output-stationary: every 64 x 64 block of dW2 / 64 x 96 block of dW1 has a few owners that split the ROWS between
-// them (split-K), so the partials are 18 MB at any batch size and nothing is accumulated that is not also reduced.
+// them (split-K), so the partials are 7 MB at any batch size and nothing is accumulated that is not also reduced.
 //   k_policy_bwd_data   per tile: dZ2 = (W3^T dY) . lrelu'(H2), dH1 = W2^T dZ2 (MFMA), dZ1 = dH1 . lrelu'(H1), the
 //                       small gradients (db1, db2, dW3, db3); dZ2 / dZ1 leave in the forward's accumulator-fragment
 //                       order (coalesced 1 KiB stores), 67 MB at 512 tiles: L2 / Infinity-Cache resident
 //   k_policy_wgrad      dW2 += dZ2 H1^T, dW1 += dZ1 X^T: workgroup = (output block, K-slice), 4 waves interleave the row
 //                       tiles of the slice; operands come back with coalesced fragment loads and are transposed through
-//                       wave-private LDS ([feature][36], the layout of k_policy_bwd's phases C / D); every wave writes
-//                       its accumulators into the block's region of "virtual slab" (slice, wave)
+//                       wave-private LDS ([feature][36], the layout of k_policy_bwd's phases C / D); the four waves' sums
+//                       meet in LDS (fixed order) and go to the block's region of "virtual slab" `slice`
 //   k_grad_reduce       unchanged: fixed-order sum of the virtual slabs -> flat Flux-order gradient (bitwise reproducible)
 #include "ppo_internal.h"
 #include "ppo_device.h"
@@ -51,6 +51,17 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
     __syncthreads();
     const float4* const w2t = a.w2tp + (size_t)w * S4 * 64 + lane;     // this wave's W2^T tile
     const unsigned fb = (unsigned)(32 * w + 4 * h);
+    // the tile's inputs are fetched one tile ahead (first tile: before the loop): a workgroup walks only a few tiles and
+    // an HBM / L2 round trip per tile in front of phase A is a third of the tile's time
+    float4 n1[4], n2[4], ndy = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch_tile = [&](int64_t t) {
+        const float4* s1 = a.act1 + ((size_t)t * NT + w) * 4 * 64 + lane;
+        const float4* s2 = a.act2 + ((size_t)t * NT + w) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { n2[q] = s2[q * 64]; n1[q] = s1[q * 64]; }
+        ndy = a.dY[(size_t)t * 32 + j];
+    };
+    if ((int64_t)blockIdx.x < a.B) fetch_tile(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
         unsigned lb = fb * LD + j;
         asm volatile("" : "+v"(lb));                                   // per-tile opaque base (see k_policy_bwd)
@@ -60,11 +71,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
         const float* const w3b = sW3 + fb * 4;
         // ---- phase A: dZ2 of feature tile w
         float4 v1[4], v2[4];
-        const float4* s1 = a.act1 + ((size_t)tile * NT + w) * 4 * 64 + lane;
-        const float4* s2 = a.act2 + ((size_t)tile * NT + w) * 4 * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { v2[q] = s2[q * 64]; v1[q] = s1[q * 64]; }
-        const float4 dy = a.dY[(size_t)tile * 32 + j];
+        for (int q = 0; q < 4; ++q) { v2[q] = n2[q]; v1[q] = n1[q]; }
+        const float4 dy = ndy;
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
         float4* const zo = a.dz2f + ((size_t)tile * NT + w) * 4 * 64 + lane;
 #pragma unroll
@@ -84,6 +93,16 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
         }
         __syncthreads();
         // ---- phase B: small grads of feature 32w + j (rows 16h .. 16h+15), dH1 tile w = W2^T dZ2, dZ1
+        // W2^T stream (L2-resident): two register sets of PF fragment groups, ping-ponged -- the loads of one set are
+        // issued BEFORE the MFMAs that consume the other (sched_barrier pins that order, see k_policy_bwd); the first
+        // set and the next tile's inputs go out in front of the small VALU gradient sums
+        constexpr int PF = 4;
+        static_assert(S4 % (2 * PF) == 0, "ring sets");
+        float4 ringA[PF], ringB[PF];
+#pragma unroll
+        for (int g = 0; g < PF; ++g) ringA[g] = w2t[(size_t)g * 64];
+        if (tile + gridDim.x < a.B) fetch_tile(tile + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
         {
             const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
@@ -112,25 +131,34 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
-            constexpr int PF = 4;
-            float4 ring[PF];
+            auto mfma_set = [&](const float4 (&rg)[PF]) {
 #pragma unroll
-            for (int g = 0; g < PF; ++g) ring[g] = w2t[(size_t)g * 64];
-#pragma unroll 2
-            for (int s0 = 0; s0 < S4; s0 += PF) {
-                float4 cur[PF];
-#pragma unroll
-                for (int g = 0; g < PF; ++g) { cur[g] = ring[g]; ring[g] = w2t[(size_t)(s0 + PF + g) * 64]; }   // tail padding covers the over-read
-#pragma unroll
-                for (int g = 0; g < PF; ++g) {
+                for (int u = 0; u < PF; ++u) {
                     float b[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * (s0 + g) + 2 * e) * LD];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].x, b[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].y, b[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].z, b[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[g].w, b[3], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
                 }
+                bz += 8 * PF * LD;
+            };
+            const float4* wn = w2t + (size_t)PF * 64;
+#pragma unroll 1
+            for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringB[u] = wn[(size_t)u * 64];
+                wn += (size_t)PF * 64;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringA[u] = wn[(size_t)u * 64];      // tail padding covers the over-read
+                wn += (size_t)PF * 64;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringB);
+                __builtin_amdgcn_sched_barrier(0);
             }
             float4* const z1o = a.dz1f + ((size_t)tile * NT + w) * 4 * 64 + lane;
 #pragma unroll
@@ -200,7 +228,14 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
     const int block = blockIdx.x % (NB2 + NB1), slice = blockIdx.x / (NB2 + NB1);
     const int64_t per = (a.B + a.ksplit - 1) / a.ksplit;
     const int64_t t0 = (int64_t)slice * per, t1 = (t0 + per < a.B) ? t0 + per : a.B;
-    float* slab = a.slabs + (size_t)(slice * 4 + v) * a.slab_stride;
+    float* slab = a.slabs + (size_t)slice * a.slab_stride;             // one partial per K-slice: the four waves' sums meet in LDS
+    const float* const red0 = smem;                                    // wave u's accumulators at red0 + u * WT * TILE
+    // fixed-order in-workgroup sum: every wave parks its accumulators [reg][lane] in its own LDS tiles, then wave v adds
+    // registers [v R/4, (v+1) R/4) of the four waves in wave order (bitwise reproducible)
+    auto wg_sum = [&](int r) {
+        return ((red0[(size_t)0 * WT * TILE + r * 64 + lane] + red0[(size_t)1 * WT * TILE + r * 64 + lane]) +
+                red0[(size_t)2 * WT * TILE + r * 64 + lane]) + red0[(size_t)3 * WT * TILE + r * 64 + lane];
+    };
     float* sW2 = slab;
     float* sW1 = slab + (size_t)HID * HID;
     if (block < NB2) {
@@ -250,13 +285,20 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next tile overwrites the buffers
         }
+        static_assert(64 * 64 <= WT * TILE, "accumulators fit the wave's LDS tiles");
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sW2[((size_t)((2 * fbk + x) * NT + (2 * kbk + y)) * 16 + r) * 64 + lane] = acc[x][y][r];
+                for (int r = 0; r < 16; ++r) bufA[((x * 2 + y) * 16 + r) * 64 + lane] = acc[x][y][r];
+        __syncthreads();
+        {   // wave v owns tile (x, y) = (v >> 1, v & 1) of the block
+            const int x = v >> 1, y = v & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sW2[((size_t)((2 * fbk + x) * NT + (2 * kbk + y)) * 16 + r) * 64 + lane] = wg_sum(v * 16 + r);
+        }
     } else {
         // ---------------- dW1 block: k-tile kb x all NI input tiles (columns >= F are zero padding)
         const int kbk = block - NB2;
@@ -311,8 +353,14 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
 #pragma unroll
         for (int y = 0; y < NI; ++y)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sW1[((size_t)(kbk * NI + y) * 16 + r) * 64 + lane] = acc[y][r];
+            for (int r = 0; r < 16; ++r) bufA[(y * 16 + r) * 64 + lane] = acc[y][r];
+        __syncthreads();
+        constexpr int RQ = 16 * NI / 4;                                // registers per wave of the final sum
+#pragma unroll
+        for (int rr = 0; rr < RQ; ++rr) {
+            const int r = v * RQ + rr;                                 // = y * 16 + reg
+            sW1[((size_t)(kbk * NI + r / 16) * 16 + (r % 16)) * 64 + lane] = wg_sum(r);
+        }
     }
 }
 
@@ -329,12 +377,11 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     }
     const int nwg = (int)(a.B < 256 ? a.B : 256);
     constexpr int blocks = (NT / 2) * (NT / 2) + NT;
-    // K-slices: two workgroups per CU over the block list, but never more virtual slabs (4 per slice) than the buffer holds
-    int ks = (512 + blocks - 1) / blocks;
-    if (ks * 4 > 256) ks = 64;
+    // K-slices: two workgroups per CU over the block list, all resident at once (a partial second round costs a whole one)
+    int ks = 512 / blocks;
     if ((int64_t)ks > a.B) ks = (int)a.B;
     a.ksplit = ks;
-    p->nwg_bwd = ks * 4;             // slabs holding weight-gradient partials
+    p->nwg_bwd = ks;                 // slabs holding weight-gradient partials (one per K-slice)
     p->nwg_small = nwg;              // slabs holding the small-gradient tails
     {
         ProfScope ps("k_policy_bwd_data");
