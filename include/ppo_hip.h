@@ -212,7 +212,7 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
 /* Which backward kernel a minibatch takes (same gradient, different reduction tree: results agree to fp32 rounding):
  * up to `tiles` 32-row tiles the three-product form (dZ kernel + output-stationary split-K weight-gradient kernel: no
  * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
- * keeps every weight gradient resident in MFMA accumulators.  Default 1536 (-1 restores it), 0 = always fused. */
+ * keeps every weight gradient resident in MFMA accumulators.  Default 384 (-1 restores it), 0 = always fused. */
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
 /* Likewise for the train forward: minibatches of up to `states` states (H = 32) give every state to 2 or 4 waves instead
  * of one, so a minibatch smaller than the chip's 1024 SIMDs still fills it (logits agree with the one-wave kernel to

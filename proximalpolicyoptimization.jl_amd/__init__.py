@@ -106,7 +106,7 @@ def set_rollout_compact(on=None):
 
 def set_bwd_small_max_tiles(tiles=None):
     """Minibatches of up to `tiles` 32-row tiles use the three-product backward (no per-workgroup gradient slabs), larger
-    ones the fused kernel.  None = default (1536), 0 = always the fused kernel."""
+    ones the fused kernel.  None = default (384), 0 = always the fused kernel."""
     call("ppo_set_bwd_small_max_tiles", -1 if tiles is None else int(tiles))
 
 

@@ -736,11 +736,12 @@ int32_t ppo_rollouts_compute_gae(ppo_rollouts_t ro, const float* values, double 
     return PPO_OK;
 }
 
-// minibatches up to this many 32-row tiles take the three-product backward (ppo_policy_bwd_small.hip); measured
-// cross-over with the fused kernel on MI355X.  PPO_BWD_SMALL_MAX_TILES overrides (0 = never).
-static int64_t g_bwd_small_max_tiles = [] { const char* v = std::getenv("PPO_BWD_SMALL_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)1536; }();
+// minibatches up to this many 32-row tiles take the three-product backward (ppo_policy_bwd_small.hip).  Measured on
+// MI355X (HID = 256): 7.6 % faster per PPO iteration at 256 tiles, level with the fused kernel at
+// 512, 6 % slower at 1024 -- so the default switches between the two at 384.  PPO_BWD_SMALL_MAX_TILES overrides (0 = never).
+static int64_t g_bwd_small_max_tiles = [] { const char* v = std::getenv("PPO_BWD_SMALL_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)384; }();
 
-int32_t ppo_set_bwd_small_max_tiles(int64_t tiles) { g_bwd_small_max_tiles = tiles < 0 ? 1536 : tiles; return PPO_OK; }
+int32_t ppo_set_bwd_small_max_tiles(int64_t tiles) { g_bwd_small_max_tiles = tiles < 0 ? 384 : tiles; return PPO_OK; }
 
 // ================================================================ training
 // B = number of 32-row tiles of the minibatch (states * H/32)
@@ -750,10 +751,6 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
     const size_t NT = p->HID / 32;
     PPO_TRY(p->act1.alloc((size_t)B * NT * 1024)); PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
     PPO_TRY(p->dY.alloc((size_t)B * 128)); PPO_TRY(p->loss_terms.alloc((size_t)B * 2));
-    if (p->dtype == PPO_DTYPE_F32 && g_bwd_small_max_tiles > 0) {      // dZ2 / dZ1 of the small-minibatch backward
-        const size_t bs = (size_t)std::min<int64_t>(B, g_bwd_small_max_tiles);
-        PPO_TRY(p->dz2f.alloc(bs * NT * 1024)); PPO_TRY(p->dz1f.alloc(bs * NT * 1024));
-    }
     // one gradient slab per backward workgroup: 256, or 512 where two workgroups share a CU (fp32 HID = 128, F = 72)
     PPO_TRY(p->slabs.alloc((size_t)((p->HID == 128 && p->F == 72) ? 512 : 256) * slab_floats(p->F, p->HID)));
     PPO_TRY(p->idx.alloc((size_t)B));
@@ -778,7 +775,11 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew, adv));
     // small minibatches: three-product backward (no per-workgroup gradient slabs); otherwise the fused kernel
     int32_t bs = PPO_ERR_UNSUPPORTED;
-    if (B * (ro->H / 32) <= g_bwd_small_max_tiles) bs = launch_policy_bwd_small(pol, ro, idx_dev, B);
+    if (B * (ro->H / 32) <= g_bwd_small_max_tiles && pol->dtype == PPO_DTYPE_F32) {
+        const size_t frag = (size_t)B * (ro->H / 32) * (pol->HID / 32) * 1024;     // dZ2 / dZ1 in fragment order, like act1 / act2
+        PPO_TRY(pol->dz2f.alloc(frag)); PPO_TRY(pol->dz1f.alloc(frag));
+        bs = launch_policy_bwd_small(pol, ro, idx_dev, B);
+    }
     if (bs != PPO_OK && bs != PPO_ERR_UNSUPPORTED) return bs;
     if (bs == PPO_ERR_UNSUPPORTED) PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
     PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));

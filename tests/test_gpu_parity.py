@@ -300,13 +300,13 @@ def storage_mode(request, P):
     P.set_rollout_compact(None)
 
 
-@pytest.fixture(params=[0, None], ids=["large-batch-kernels", "small-batch-kernels"])
+@pytest.fixture(params=[0, 4096], ids=["large-batch-kernels", "small-batch-kernels"])
 def bwd_form(request, P):
     """Both kernel sets at test sizes: the fused backward + one-wave-per-state train forward (forced), and what small
     minibatches take by default: the three-product backward and the 2 / 4-waves-per-state train forward
     (ppo_set_bwd_small_max_tiles, ppo_set_fwd_split_max_states)."""
     P.set_bwd_small_max_tiles(request.param)
-    P.set_fwd_split_max_states(request.param)
+    P.set_fwd_split_max_states(min(request.param, 512))
     yield request.param
     P.set_bwd_small_max_tiles(None)
     P.set_fwd_split_max_states(None)
