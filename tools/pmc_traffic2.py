@@ -30,7 +30,7 @@ def passes(d):
 res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --t-steps 8 --epochs 1 at each launch shape; "
                  "FETCH_SIZE doubled (gfx950 wide-read correction)", "launch_shapes": {}}
 for arg in sys.argv[2:]:
-    key, d = arg.split("=", 1)
+    key, d = arg.rsplit("=", 1)
     ks = passes(d)
     bwd = [v for k, v in ks.items() if k.startswith("k_policy_bwd")]
     res["launch_shapes"][key] = {"k_policy_bwd_hbm_bytes": (bwd[0]["hbm_bytes"] if bwd else None), "kernels": ks}
