@@ -100,7 +100,7 @@ def set_rollout_persistent(on=None):
 def set_rollout_compact(on=None):
     """State storage of engine-collected rollouts: True = compact env snapshots (64 B per transition for Q = 8; the train
     forward re-derives the observation rows), False = expanded observations (2304 B), None = automatic (compact above
-    4 GiB of expanded states or while streaming to disk).  Bit-identical results either way."""
+    32 GiB of expanded states or while streaming to disk).  Bit-identical results either way."""
     call("ppo_set_rollout_compact", -1 if on is None else int(bool(on)))
 
 

@@ -295,14 +295,16 @@ static int g_rollout_persistent = [] { const char* v = std::getenv("PPO_ROLLOUT_
 int32_t ppo_set_rollout_persistent(int32_t mode) { g_rollout_persistent = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
 
 // state storage of engine-collected rollouts: -1 = automatic (compact env snapshots when the expanded observations of
-// the requested rollout would exceed PPO_COMPACT_AUTO_BYTES -- default 4 GiB -- or when a disk sink is attached: the
-// stream then carries 64 + 4 instead of 2304 + 4 state bytes per env-step for Q = 8), 0 = always expanded, 1 = always compact
+// the requested rollout would exceed PPO_COMPACT_AUTO_BYTES -- default 32 GiB: re-deriving the rows costs the train
+// forward 3 % in fp32 and 17 % in bf16 mode, so below that the 288 GB of HBM are spent on speed -- or when a disk sink is
+// attached: the stream then carries 64 + 4 instead of 2304 + 4 state bytes per env-step for Q = 8), 0 = always
+// expanded, 1 = always compact
 static int g_rollout_compact = [] { const char* v = std::getenv("PPO_ROLLOUT_COMPACT"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; }();
 int32_t ppo_set_rollout_compact(int32_t mode) { g_rollout_compact = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
 static bool want_compact(const ppo_rollouts_s* ro, int64_t T) {
     if (g_rollout_compact >= 0) return g_rollout_compact == 1;
     if (ro->sink) return true;
-    static const double limit = [] { const char* v = std::getenv("PPO_COMPACT_AUTO_BYTES"); return v ? atof(v) : 4.0 * 1024 * 1024 * 1024; }();
+    static const double limit = [] { const char* v = std::getenv("PPO_COMPACT_AUTO_BYTES"); return v ? atof(v) : 32.0 * 1024 * 1024 * 1024; }();
     return (double)T * (double)ro->N * ro->H * ro->F > limit;
 }
 
@@ -361,19 +363,70 @@ int32_t ppo_env_get_internal(ppo_env_t env, int8_t* score, int8_t* degree, int32
 }
 
 // ================================================================ policy
-int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers, int32_t out_per_edge,
+// Hidden widths other than 128 / 256 run on the next wider kernel with ZERO-PADDED hidden units.  That is exact, not an
+// approximation: a padded unit has zero input weights and zero bias, so its activation is leakyrelu(0) = 0; its outgoing
+// weights are zero, so it adds fmaf(0, 0, acc) = acc to every sum it enters; and every gradient that touches it carries
+// one of those zeros as a factor (dZ2[pad] = (W3^T dY)[pad] = 0, H1[pad] = 0, dH1[pad] = (W2^T dZ2)[pad] = 0), so Adam
+// (m = v = 0 -> update 0 / (sqrt(0) + eps) = 0) never moves it.  The caller sees its own Policy(F, hidden, 2, 4): the flat
+// Flux-order vectors that cross the ABI (parameters, gradient, Adam moments) have the caller's layout.
+static __host__ __device__ inline int64_t np_of(int64_t F, int64_t hid) { return hid * F + hid + hid * hid + hid + (int64_t)PPO_OUT * hid + PPO_OUT; }
+
+// index of the caller's flat element i (width hu) in the flat vector at width hp
+__device__ __forceinline__ int64_t pad_index(int64_t i, int F, int hu, int hp) {
+    const int64_t uW2 = (int64_t)hu * F + hu, ub2 = uW2 + (int64_t)hu * hu, uW3 = ub2 + hu;
+    const int64_t pW2 = (int64_t)hp * F + hp, pb2 = pW2 + (int64_t)hp * hp, pW3 = pb2 + hp;
+    if (i < (int64_t)hu * F) return (i % hu) + (int64_t)hp * (i / hu);                  // W1[o][k]
+    if (i < uW2) return (int64_t)hp * F + (i - (int64_t)hu * F);                        // b1
+    if (i < ub2) { const int64_t e = i - uW2; return pW2 + (e % hu) + (int64_t)hp * (e / hu); }   // W2[o][k]
+    if (i < uW3) return pb2 + (i - ub2);                                               // b2
+    return pW3 + (i - uW3);                                                            // W3[4][k] (k < hu), b3: b3 follows W3
+}
+__global__ void k_pad_copy(float* __restrict__ user, float* __restrict__ padded, int64_t n_user, int F, int hu, int hp, int to_user) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_user) return;
+    // b3 sits behind W3 in both layouts, but W3 is [4][hid]: the last 4 elements are b3
+    const int64_t pi = (i >= n_user - PPO_OUT) ? (np_of(F, hp) - (n_user - i)) : pad_index(i, F, hu, hp);
+    if (to_user) user[i] = padded[pi]; else padded[pi] = user[i];
+}
+// host flat vector (caller's layout) <-> device flat vector at the kernels' width
+static int32_t flat_to_device(ppo_policy_s* p, const float* host, float* dev_padded) {
+    if (p->hid_user == p->HID) return h2d(dev_padded, host, (size_t)p->np);
+    DevBuf<float> tmp;
+    PPO_TRY(tmp.alloc((size_t)p->np_user));
+    PPO_TRY(h2d(tmp.p, host, (size_t)p->np_user));
+    HIP_TRY(hipMemsetAsync(dev_padded, 0, (size_t)p->np * sizeof(float), g_stream));
+    hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((p->np_user + 255) / 256)), dim3(256), 0, g_stream, tmp.p, dev_padded,
+                       p->np_user, p->F, p->hid_user, p->HID, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return PPO_OK;
+}
+static int32_t flat_to_host(ppo_policy_s* p, float* host, const float* dev_padded) {
+    if (p->hid_user == p->HID) return d2h(host, dev_padded, (size_t)p->np);
+    DevBuf<float> tmp;
+    PPO_TRY(tmp.alloc((size_t)p->np_user));
+    hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((p->np_user + 255) / 256)), dim3(256), 0, g_stream, tmp.p,
+                       const_cast<float*>(dev_padded), p->np_user, p->F, p->hid_user, p->HID, 1);
+    HIP_TRY(hipGetLastError());
+    return d2h(host, tmp.p, (size_t)p->np_user);
+}
+
+int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_layers, int32_t out_per_edge,
                           ppo_policy_t* out) {
     PPO_TRY(ensure_init());
     ARG_CHECK(out, "policy_create: null out");
-    if (num_hidden_layers != 2 || out_per_edge != PPO_OUT ||
-        !((F == 72 && (hidden == 256 || hidden == 128)) || (F == 216 && hidden == 128))) {
-        ppo_set_error("policy_create: the gfx950 kernels are built for Policy(72|216, 128|256, 2, 4) "
-                      "(test/test_square_mesh.jl:29, test/output/*.bson, BASELINE config 2)");
+    const int32_t hidden = hidden_user <= 128 ? 128 : 256;                  // width of the kernels that run it
+    if (num_hidden_layers != 2 || out_per_edge != PPO_OUT || hidden_user < 1 || hidden_user > 256 ||
+        !(F == 72 || (F == 216 && hidden == 128))) {
+        ppo_set_error("policy_create: the gfx950 kernels cover Policy(72, 1..256, 2, 4) and Policy(216, 1..128, 2, 4) "
+                      "(test/test_square_mesh.jl:29, test/output/*.bson, BASELINE config 2); hidden widths other than "
+                      "128 / 256 run zero-padded on the next wider kernel");
         return PPO_ERR_UNSUPPORTED;
     }
     ppo_policy_s* p = new ppo_policy_s();
     p->F = F; p->HID = hidden; p->L = num_hidden_layers; p->OUT = out_per_edge;
-    p->np = (int64_t)hidden * F + hidden + (int64_t)hidden * hidden + hidden + (int64_t)PPO_OUT * hidden + PPO_OUT;
+    p->hid_user = hidden_user; p->np_user = np_of(F, hidden_user);
+    p->np = np_of(F, hidden);
     int32_t s = PPO_OK;
     if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F + PPO_PACK_PAD)) || (s = p->w2p.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) ||
         (s = p->w2tp.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) || (s = p->b1p.alloc(hidden)) || (s = p->b2p.alloc(hidden)) ||
@@ -406,15 +459,15 @@ int32_t ppo_policy_set_dtype(ppo_policy_t pol, int32_t dtype) {
 int32_t ppo_policy_get_dtype(ppo_policy_t pol, int32_t* dtype) { ARG_CHECK(pol && dtype, "null"); *dtype = pol->dtype; return PPO_OK; }
 
 int32_t ppo_policy_destroy(ppo_policy_t pol) { if (pol) { (void)hipStreamSynchronize(g_stream); delete pol; } return PPO_OK; }
-int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n) { ARG_CHECK(pol && n, "null"); *n = pol->np; return PPO_OK; }
+int32_t ppo_policy_num_params(ppo_policy_t pol, int64_t* n) { ARG_CHECK(pol && n, "null"); *n = pol->np_user; return PPO_OK; }
 
 int32_t ppo_policy_set_params(ppo_policy_t pol, const float* flat) {
     ARG_CHECK(pol && flat, "set_params: null");
-    PPO_TRY(h2d(pol->params.p, flat, (size_t)pol->np));
+    PPO_TRY(flat_to_device(pol, flat, pol->params.p));
     return launch_pack_params(pol);
 }
-int32_t ppo_policy_get_params(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_params: null"); return d2h(flat, pol->params.p, (size_t)pol->np); }
-int32_t ppo_policy_get_grad(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_grad: null"); return d2h(flat, pol->grad.p, (size_t)pol->np); }
+int32_t ppo_policy_get_params(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_params: null"); return flat_to_host(pol, flat, pol->params.p); }
+int32_t ppo_policy_get_grad(ppo_policy_t pol, float* flat) { ARG_CHECK(pol && flat, "get_grad: null"); return flat_to_host(pol, flat, pol->grad.p); }
 int32_t ppo_policy_grad_buffer_dev(ppo_policy_t pol, void** dev_ptr, int64_t* n_floats) {
     ARG_CHECK(pol && dev_ptr && n_floats, "grad_buffer_dev: null");
     *dev_ptr = pol->grad.p; *n_floats = pol->np + 2;
@@ -452,15 +505,15 @@ int32_t ppo_adam_get_lr(ppo_adam_t opt, double* eta) { ARG_CHECK(opt && eta, "nu
 int32_t ppo_adam_set_lr(ppo_adam_t opt, double eta) { ARG_CHECK(opt, "null"); opt->eta = eta; return PPO_OK; }
 int32_t ppo_adam_get_state(ppo_adam_t opt, float* m, float* v, double* bp) {
     ARG_CHECK(opt, "null");
-    if (m) PPO_TRY(d2h(m, opt->m.p, (size_t)opt->pol->np));
-    if (v) PPO_TRY(d2h(v, opt->v.p, (size_t)opt->pol->np));
+    if (m) PPO_TRY(flat_to_host(opt->pol, m, opt->m.p));
+    if (v) PPO_TRY(flat_to_host(opt->pol, v, opt->v.p));
     if (bp) { bp[0] = opt->beta_pow[0]; bp[1] = opt->beta_pow[1]; }
     return PPO_OK;
 }
 int32_t ppo_adam_set_state(ppo_adam_t opt, const float* m, const float* v, const double* bp) {
     ARG_CHECK(opt, "null");
-    if (m) PPO_TRY(h2d(opt->m.p, m, (size_t)opt->pol->np));
-    if (v) PPO_TRY(h2d(opt->v.p, v, (size_t)opt->pol->np));
+    if (m) PPO_TRY(flat_to_device(opt->pol, m, opt->m.p));
+    if (v) PPO_TRY(flat_to_device(opt->pol, v, opt->v.p));
     if (bp) { opt->beta_pow[0] = bp[0]; opt->beta_pow[1] = bp[1]; }
     return PPO_OK;
 }

@@ -75,8 +75,10 @@ struct ppo_env_s {
 };
 
 struct ppo_policy_s {
-    int32_t F, HID, L, OUT;
-    int64_t np;
+    int32_t F, HID, L, OUT;            // HID: the width the kernels run (128 or 256)
+    int32_t hid_user = 0;              // hidden_channels the caller asked for (<= HID): the missing units are zero-padded
+    int64_t np_user = 0;               // parameter count of the caller's Policy (what crosses the ABI)
+    int64_t np;                        // parameter count at width HID (device buffers, all-reduce)
     // canonical flat parameters (Flux order) + packed MFMA-fragment copies
     DevBuf<float> params;              // [np]
     DevBuf<float> w1p, w2p, w2tp;      // A-operand fragment order

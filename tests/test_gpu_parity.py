@@ -257,6 +257,63 @@ def test_policy_forward(P, orc, golden_dir, F, HID, fixture):
     assert np.array_equal(single, probs[0])
 
 
+@pytest.mark.parametrize("hid", [64, 96, 160, 224, 50, 1])
+def test_policy_any_hidden_width(P, orc, hid):
+    """SimplePolicy.Policy(72, hidden, 2, 4) for hidden widths the kernels are not built for (test/policy.jl:9-19 takes any):
+    the engine runs them zero-padded on the 128 / 256 kernels, which is exact -- multiples of 32 reproduce the
+    device-order oracle at the caller's width bit for bit (rollout: actions, probabilities), every width matches the
+    float64 oracle's gradient, and what crosses the ABI (parameters, gradient, Adam moments) has the caller's layout."""
+    env = P.HipVecEnv(num_envs=16, Q=8, max_actions=9, seed=23)
+    pol = P.HipPolicy(72, hid, 2, 4, seed=hid)
+    n_user = 72 * hid + hid + hid * hid + hid + 4 * hid + 4
+    assert pol.num_params == n_user
+    rng = np.random.default_rng(hid)
+    p0 = (pol.params + (rng.normal(size=n_user) * 0.05).astype(np.float32)).astype(np.float32)
+    pol.params = p0
+    assert np.array_equal(pol.params, p0), "parameters round-trip in the caller's Flux layout"
+    ro = P.BufferRollouts()
+    P.collect_rollouts_steps_(ro, env, pol, 10, 1.0)
+    st, act = ro.state_data
+    if hid % 32 == 0:
+        oenv = orc.Env(Q=8, max_actions=9, N=16, seed=23)
+        oenv.reset()
+        ref = orc.collect_rollouts_tn(oenv, p0, hid, 10, mode_dev=True)
+        assert np.array_equal(ro.selected_actions - 1, ref["actions"]) and np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
+    else:
+        for t, n in ((0, 0), (5, 3), (9, 15)):
+            pr = orc.action_probabilities(p0, 72, hid, st[t, n], act[t, n], "ref")
+            a = int(ro.selected_actions[t, n]) - 1
+            assert abs(ro.selected_action_probabilities[t, n] - pr[a]) <= 2e-5 * pr[a] + 1e-8
+    ds = P.construct_dataset(ro)
+    sel = rng.permutation(len(ds))[:100] + 1
+    for small in (0, 4096):                       # both kernel sets
+        P.set_bwd_small_max_tiles(small); P.set_fwd_split_max_states(min(small, 512))
+        try:
+            lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01)
+        finally:
+            P.set_bwd_small_max_tiles(None); P.set_fwd_split_max_states(None)
+        g = pol.grad()
+        assert g.shape == (n_user,)
+        s0 = sel - 1
+        g64, olp, ole = orc.step_batch_grad_f64(p0, 72, hid, st.reshape(-1, 32, 72)[s0], act.reshape(-1)[s0],
+                                                (ro.selected_actions.reshape(-1)[s0] - 1).astype(np.int32),
+                                                ro.selected_action_probabilities.reshape(-1)[s0], ro.rewards.reshape(-1)[s0], 0.05, 0.01)
+        assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+        assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    # training: Adam on the caller's parameters equals the oracle's Adam on them (the padded units never move)
+    opt = P.Optimiser(P.Adam(1e-3))
+    P.step_batch_(pol, opt, ds, sel, 0.05, 0.01)
+    m, v, bp = opt.members[0].get_state()
+    assert m.shape == v.shape == (n_user,)
+    pp, mm, vv, bb = p0.copy(), np.zeros_like(p0), np.zeros_like(p0), np.array([0.9, 0.999])
+    orc.adam_step(pp, pol.grad(), mm, vv, bb, 1e-3)
+    assert np.array_equal(pol.params, pp) and np.array_equal(m, mm) and np.array_equal(v, vv)
+    with pytest.raises(P.PPOError):
+        P.HipPolicy(72, 300, 2, 4)
+    with pytest.raises(P.PPOError):
+        P.HipPolicy(72, 128, 3, 4)
+
+
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
 @pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10)])
 def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_mode):
