@@ -253,6 +253,7 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
  * distributes the 128-byte unique id between its ranks (rank 0 calls ppo_rccl_unique_id, every rank ppo_rccl_init
  * after ppo_device_init), runs ppo_rccl_self_test collectively, and passes ppo_rccl_allreduce as the `allreduce`
  * argument of ppo_train.  Replaces, on the reference side, nothing: the reference is single-process. */
+int32_t ppo_rccl_probe(void);                      /* local: can librccl be resolved?  agree on it before ppo_rccl_init */
 int32_t ppo_rccl_unique_id(uint8_t* out128);
 int32_t ppo_rccl_init(int32_t rank, int32_t world, const uint8_t* id128);
 int32_t ppo_rccl_allreduce(void* ctx, void* grad_dev, int64_t n_floats);      /* a ppo_allreduce_fn */

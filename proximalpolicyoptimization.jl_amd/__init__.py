@@ -974,6 +974,12 @@ def _native_rccl_hook_impl(rank, world):
 
     why = ""
     uid = np.zeros(128, np.uint8)
+    # stage 0: every rank must be able to resolve RCCL before any rank enters the collective ncclCommInitRank
+    probe = lib().ppo_rccl_probe() == 0
+    if not all_ok(probe):
+        sys.stderr.write("rank %d: native RCCL hook not adopted (librccl %s here); every rank uses the torch.distributed hook\n"
+                         % (rank, "resolved" if probe else "not found"))
+        return None
     if rank == 0:
         try:
             call("ppo_rccl_unique_id", uid.ctypes.data_as(C.c_void_p))

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ppo_profile_returns": [C.c_int64, C.c_int64, C.c_double, C.c_int32, c_f64p],
     "ppo_profile_gae": [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p],
     "ppo_rollouts_compute_gae": [H, c_f32p, C.c_double, C.c_double, c_f32p, c_f32p],
+    "ppo_rccl_probe": [],
     "ppo_rccl_unique_id": [C.c_void_p],
     "ppo_rccl_init": [C.c_int32, C.c_int32, C.c_void_p],
     "ppo_rccl_allreduce": [C.c_void_p, C.c_void_p, C.c_int64],

@@ -53,16 +53,28 @@ struct BwdArgs {
 // unless a SECOND workgroup shares the CU.  Registers allow it (~220 per wave); LDS did not (86.5 KB).  So in this
 // shape X^T is staged as int8 (2.3 KB instead of 9.2 KB as floats; the B operands of phase D are converted on the way
 // in, 8 VALU per 16-byte read), which brings the workgroup to 79.6 KB: two per CU, 512 workgroups per launch.
+// How the state rows X reach phase D's B operands (F = 72 only; the 8 tail columns always go through sXt as floats):
+//   0  X^T as floats [feature][36 rows]: 288 cvt pairs + 288 ds_write_b32 per wave and tile, 8 ds_read_b128 in phase D
+//   1  X^T as int8   [feature][36 rows]: 288 ds_write_b8, 8 ds_read_b32 + 32 cvt in phase D
+//   2  X   as int8   [row][68 B] (the rows as they come): 64 ds_write_b32, 32 ds_read_i8 + 32 cvt in phase D
+// Every vector instruction beside an fp32 MFMA costs MFMA time on gfx950, so the forms differ by
+// what they issue, not by what they compute.
+#ifndef PPO_BWD_XMODE
+#define PPO_BWD_XMODE 2
+#endif
 template <int F, int HID>
 struct BwdCfg {
-    static constexpr bool XI8 = (HID == 128 && F == 72);
-    static constexpr int WG_PER_CU = XI8 ? 2 : 1;
-    static constexpr int MIN_WAVES = (HID >= 256 || XI8) ? 2 : 1;       // per SIMD (caps the register budget at 256)
+    static constexpr int XMODE = (F == 72) ? ((HID == 128 && PPO_BWD_XMODE == 0) ? 1 : PPO_BWD_XMODE) : 0;   // HID = 128 needs an int8 form (LDS)
+    static constexpr bool XI8 = XMODE == 1, XN8 = XMODE == 2;
+    static constexpr int XS = 68;                                        // XN8 row stride in bytes (17 dwords: rows 16 apart sit 16 banks apart)
+    static constexpr int WG_PER_CU = (HID == 128 && F == 72) ? 2 : 1;
+    static constexpr int MIN_WAVES = (HID >= 256 || WG_PER_CU == 2) ? 2 : 1;   // per SIMD (caps the register budget at 256)
 };
 
 template <int F, int HID>
 __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy_bwd(BwdArgs a) {
-    constexpr bool XI8 = BwdCfg<F, HID>::XI8;
+    constexpr bool XI8 = BwdCfg<F, HID>::XI8, XN8 = BwdCfg<F, HID>::XN8;
+    constexpr int XS = BwdCfg<F, HID>::XS;
     constexpr int NT = HID / 32;                // feature tiles == waves per workgroup (wave w owns tile w)
     constexpr int NTHR = NT * 64;
     constexpr int FP = ((F + 31) / 32) * 32;
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     float* sZ1 = sH2 + HID * LD;                // [HID][33]  dZ1^T
     float* sX = sZ1 + HID * LD;                 // [NIM*32][33]  X^T (float), MFMA part  (XI8: int8 [NIM*32][LD bytes])
     int8_t* const sXb = reinterpret_cast<int8_t*>(sX);
-    float* sXt = XI8 ? sX + NIM * 32 * LD / 4 : sX + NIM * 32 * LD;   // [32][FT]      X tail columns, row-major per tile row
+    float* sXt = XN8 ? sX + 32 * XS / 4 : (XI8 ? sX + NIM * 32 * LD / 4 : sX + NIM * 32 * LD);   // [32][FT]  X tail columns, row-major per tile row
     float* sDY = sXt + 32 * (FT > 0 ? FT : 4);  // [32][4]
     float* sW3 = sDY + 32 * 4;                  // [HID][4]   W3[:,f] per feature (staged once)
 
@@ -230,6 +242,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
             const int d = tid + i * NTHR;                         // dword d = row*(F/4) + c : features 4c..4c+3
             if (d < XDW) {
                 const int row = d / (F / 4), c = d % (F / 4);
+                if (XN8 && 4 * c < NIM * 32) { *reinterpret_cast<uint32_t*>(sXb + row * XS + 4 * c) = xd[i]; continue; }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xv = (float)(int)(int8_t)(xd[i] >> (8 * e));
@@ -418,7 +431,10 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
 #pragma unroll
                 for (int it = 0; it < NIM; ++it) {
                     float4 b4;
-                    if (XI8) {                                   // four rows of feature 32 it + j as one dword of int8
+                    if (XN8) {                                   // feature 32 it + j of rows 16h + 4q .. +3: four sign-extending byte reads
+                        const int8_t* xb = sXb + (16 * h + 4 * q) * XS + 32 * it + j;
+                        b4 = make_float4((float)(int)xb[0], (float)(int)xb[XS], (float)(int)xb[2 * XS], (float)(int)xb[3 * XS]);
+                    } else if (XI8) {                            // four rows of feature 32 it + j as one dword of int8
                         const uint32_t d = *reinterpret_cast<const uint32_t*>(sXb + (32 * it + j) * LD + 16 * h + 4 * q);
                         b4 = make_float4((float)(int)(int8_t)(d), (float)(int)(int8_t)(d >> 8), (float)(int)(int8_t)(d >> 16), (float)(int)(int8_t)(d >> 24));
                     } else b4 = *reinterpret_cast<const float4*>(pb + 32 * it * LD + 4 * q);
@@ -489,9 +505,9 @@ extern "C" int32_t ppo_debug_bwd_stamps(unsigned long long* out) {
 
 template <int F, int HID>
 static size_t bwd_lds_bytes() {
-    const size_t xt = (size_t)(F / 32) * 32 * PPO_BWD_LD;      // X^T elements: floats, or bytes in the int8 form
-    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + (BwdCfg<F, HID>::XI8 ? xt / 4 : xt) + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 +
-                            (size_t)HID * 4);
+    const size_t xt = (size_t)(F / 32) * 32 * PPO_BWD_LD;      // X^T elements: floats, or bytes in the int8 forms
+    const size_t xfl = BwdCfg<F, HID>::XN8 ? (size_t)32 * BwdCfg<F, HID>::XS / 4 : (BwdCfg<F, HID>::XI8 ? xt / 4 : xt);
+    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + xfl + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 + (size_t)HID * 4);
 }
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {

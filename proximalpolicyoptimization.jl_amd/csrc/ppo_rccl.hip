@@ -60,6 +60,10 @@ int32_t rccl_fail(const char* what, int rc) {
 
 extern "C" {
 
+// can this process resolve RCCL at all?  (local, not collective: the host agrees on the answer BEFORE any rank enters the
+// collective ncclCommInitRank, where a rank that cannot load the library would leave the others waiting)
+int32_t ppo_rccl_probe(void) { return load_rccl(); }
+
 int32_t ppo_rccl_unique_id(uint8_t* out128) {
     ARG_CHECK(out128, "ppo_rccl_unique_id: null buffer");
     PPO_TRY(load_rccl());
