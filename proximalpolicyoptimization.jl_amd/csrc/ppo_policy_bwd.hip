@@ -42,6 +42,7 @@ struct BwdArgs {
 
     const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
     int tps;                                                // tiles per state (H / 32)
+    int stagger;                                            // experiment knob (PPO_BWD_STAGGER): the second workgroup of a CU starts late
     int x_by_tile;                                          // 1: `states` is the forward's row scratch in minibatch order
                                                             //    (tile t's rows at t*32*F: compact rollouts); 0: gather by idx
     const float4* act1; const float4* act2; const float4* dY;
@@ -59,8 +60,11 @@ struct BwdArgs {
 //   2  X   as int8   [row][68 B] (the rows as they come): 64 ds_write_b32, 32 ds_read_i8 + 32 cvt in phase D
 // Every vector instruction beside an fp32 MFMA costs MFMA time on gfx950, so the forms differ by
 // what they issue, not by what they compute.
+// Measured (gpurun_out/r2i, same box, alternating): form 0 is the fastest at HID = 256 (0.3523 vs 0.3555-0.3560 ms:
+// the byte / dword reads of forms 1-2 put their LDS latency in front of phase D's MFMAs, which costs more than the
+// 500 vector instructions they save); at HID = 128 the three are level (0.1211-0.1221 ms) and form 0 does not fit.
 #ifndef PPO_BWD_XMODE
-#define PPO_BWD_XMODE 2
+#define PPO_BWD_XMODE 0
 #endif
 template <int F, int HID>
 struct BwdCfg {
@@ -131,6 +135,8 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
     }
+    if (BwdCfg<F, HID>::WG_PER_CU == 2 && a.stagger > 0 && blockIdx.x >= 256)      // de-phase the two workgroups of a CU
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     __syncthreads();
 
     const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
@@ -520,6 +526,7 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
     a.stamps = nullptr;
+    { static const int st = [] { const char* v = std::getenv("PPO_BWD_STAGGER"); return v ? atoi(v) : 0; }(); a.stagger = st; }
 #ifdef PPO_BWD_STAMP
     { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 20 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
 #endif
