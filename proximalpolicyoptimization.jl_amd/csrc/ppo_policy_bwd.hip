@@ -42,7 +42,6 @@ struct BwdArgs {
 
     const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
     int tps;                                                // tiles per state (H / 32)
-    int stagger;                                            // experiment knob (PPO_BWD_STAGGER): the second workgroup of a CU starts late
     int x_by_tile;                                          // 1: `states` is the forward's row scratch in minibatch order
                                                             //    (tile t's rows at t*32*F: compact rollouts); 0: gather by idx
     const float4* act1; const float4* act2; const float4* dY;
@@ -135,8 +134,6 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
     }
-    if (BwdCfg<F, HID>::WG_PER_CU == 2 && a.stagger > 0 && blockIdx.x >= 256)      // de-phase the two workgroups of a CU
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     __syncthreads();
 
     const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
@@ -526,7 +523,6 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
     a.stamps = nullptr;
-    { static const int st = [] { const char* v = std::getenv("PPO_BWD_STAGGER"); return v ? atoi(v) : 0; }(); a.stagger = st; }
 #ifdef PPO_BWD_STAMP
     { static unsigned long long* dbg = nullptr; if (!dbg) (void)hipMalloc((void**)&dbg, 256 * 20 * 8); a.stamps = dbg; g_bwd_stamps = dbg; }
 #endif
