@@ -40,6 +40,14 @@
 #ifndef PPO_BF16_ACT_NT_LOAD
 #define PPO_BF16_ACT_NT_LOAD 1
 #endif
+// dW1 += dZ1^T X inside k_policy_bwd_bf16 (NI more accumulator tiles per feature tile of the wave; the dZ1 / X operand
+// fragments never leave the CU) where the registers allow it: HID = 128 (168 + 112 registers, no scratch).  At HID = 256
+// the wave already holds 256 dW2 accumulator registers and a 236-register working set: with the 96 dW1 registers hipcc
+// spills 67 (268 B of scratch per lane), so that width keeps the round-1 form: fragments to HBM + k_policy_dw1_bf16.
+#ifndef PPO_BF16_DW1_FUSED_MAX_HID
+#define PPO_BF16_DW1_FUSED_MAX_HID 128
+#endif
+#define PPO_BF16_DW1_FUSED (HID <= PPO_BF16_DW1_FUSED_MAX_HID)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -584,6 +592,16 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accW2[i][kt][r] = 0.0f;
+    constexpr bool FUSE1 = PPO_BF16_DW1_FUSED;
+    f32x16 accW1[FUSE1 ? FT : 1][FUSE1 ? NI : 1];        // dW1[k-tiles of this wave][all input tiles] (columns >= F: zero padding)
+    if (FUSE1) {
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int it = 0; it < NI; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accW1[FUSE1 ? i : 0][FUSE1 ? it : 0][r] = 0.0f;
+    }
     float db1[FT], db2[FT], dw3[FT][4];
     float4 db3 = make_float4(0.f, 0.f, 0.f, 0.f);        // per-row partial sums of dY (combined over the 32 rows at the end)
 #pragma unroll
@@ -870,6 +888,24 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                     }
                 }
             BSTAMP(6);
+            if constexpr (FUSE1) {
+            // dW1[k][i] += sum_rows dZ1[k][row] X[row][i]: both operands come back transposed from their LDS images (the
+            // fragments the HID = 256 form sends through HBM to a second kernel), NI x 2 MFMAs per feature tile
+            (void)emit_z; (void)emit_x;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 xb[NI];
+#pragma unroll
+                for (int it = 0; it < NI; ++it) xb[it] = tr_frag(imgX + trx[0] + 16 * s * STX + 64 * it, imgX + trx[1] + 16 * s * STX + 64 * it);
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    const uint4 z = tr_frag(imgZ1 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ1 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+                    db1[i] += sum_frag(z);
+#pragma unroll
+                    for (int it = 0; it < NI; ++it) accW1[FUSE1 ? i : 0][FUSE1 ? it : 0] = mfma_bf16(z, xb[it], accW1[FUSE1 ? i : 0][FUSE1 ? it : 0]);
+                }
+            }
+            } else {
             // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
             // for k_policy_dw1_bf16
 #pragma unroll
@@ -878,6 +914,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 for (int s = 0; s < 2; ++s) emit_z(i, s);
 #pragma unroll
             for (int i = 0; i < FT; ++i) emit_x(i);
+            }
         }
         __syncthreads();
         BSTAMP(7);
@@ -903,6 +940,12 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sW2[((size_t)(ft * NT + kt) * 16 + r) * 64 + lane] = accW2[i][kt][r];
+        if constexpr (FUSE1) {
+#pragma unroll
+            for (int it = 0; it < NI; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sW1[((size_t)(ft * NI + it) * 16 + r) * 64 + lane] = accW1[FUSE1 ? i : 0][FUSE1 ? it : 0][r];
+        }
         const float b1 = db1[i] + __shfl_xor(db1[i], 32), b2 = db2[i] + __shfl_xor(db2[i], 32);
         float d3[4];
 #pragma unroll
@@ -1017,7 +1060,7 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
             ProfScope ps("k_policy_bwd");                                                                         \
             hipLaunchKernelGGL((k_policy_bwd_bf16<FF, HH>), dim3(nwg), dim3(256), lds, ppo_stream(), a);       \
         }                                                                                                         \
-        {                                                                                                         \
+        if (HH > PPO_BF16_DW1_FUSED_MAX_HID) {                                                                    \
             ProfScope ps("k_policy_dw1");                                                                         \
             hipLaunchKernelGGL((k_policy_dw1_bf16<FF, HH>), dim3(nwg), dim3(HH * 2), 0, ppo_stream(), a);         \
         }                                                                                                         \
