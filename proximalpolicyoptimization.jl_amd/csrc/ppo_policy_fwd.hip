@@ -41,8 +41,17 @@ static __device__ __forceinline__ void act_store_nt(float4* p, float4 v) {
 
 // waves per SIMD: the HID=256 / F=216 instantiations need more than 256 VGPRs (128 for the layer-1
 // accumulators + operands in flight), so they run one wave per SIMD with the whole 512-entry file.
+// HID = 128, F = 72: two waves per SIMD with the deep (16-group) ring in the train forward.  Re-measured in round 2
+// (gpurun_out/r2l, train forward / 128-step rollout): 2 waves + 16 groups 0.0685 ms / 8.34 ms; 2 + 8: 0.0817 / 8.37;
+// 3 waves + 4 groups: 0.0717 / 8.87 (the rollout instantiation spills at 168 registers); 3 + 8: 0.0889 / 8.88.
+#ifndef PPO_FWD_WPS_SMALL
+#define PPO_FWD_WPS_SMALL 2          // waves per SIMD of the HID = 128, F = 72 instantiations (A/B knob)
+#endif
+#ifndef PPO_FWD_PF_SMALL_TRAIN
+#define PPO_FWD_PF_SMALL_TRAIN PPO_FWD_PF   // their train-forward ring depth
+#endif
 template <int F, int HID>
-struct FwdCfg { static constexpr int WPS = (HID >= 256 || F > 128) ? 1 : 2; };
+struct FwdCfg { static constexpr int WPS = (HID >= 256 || F > 128) ? 1 : PPO_FWD_WPS_SMALL; };
 
 // TPS = 32-row tiles per state (H = 32*TPS half-edges, A = 128*TPS actions): the wave walks the tiles of its
 // state one after the other, keeps the 4*TPS logits per lane, and runs softmax / sampling / loss once per state.
@@ -64,7 +73,8 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     constexpr int PFW = (PPO_FWD_PF < HID / 8) ? PPO_FWD_PF : HID / 8;     // at most the groups of one output tile
     // two waves per SIMD (HID = 128, F = 72): 4 groups cover the L2 latency; the train forward, whose activation stores
     // sit in the same vmcnt queue, wants the deep ring here too (0.072 -> 0.069 ms), the rollout does not (8.3 -> 8.7 ms)
-    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : ((MODE == 2 || MODE == 4) ? PFW : 4);   // weight-fragment groups kept in flight per wave
+    constexpr int PFT = (PPO_FWD_PF_SMALL_TRAIN < HID / 8) ? PPO_FWD_PF_SMALL_TRAIN : HID / 8;
+    constexpr int PF = (FwdCfg<F, HID>::WPS == 1) ? PFW : ((MODE == 2 || MODE == 4) ? PFT : 4);   // weight-fragment groups kept in flight per wave
     constexpr bool TRAIN = (MODE == 2 || MODE == 4);    // train forward: saves activations, loss tail
     constexpr bool OBS = (MODE == 3 || MODE == 4);      // the state rows are re-derived from an env snapshot in LDS
     constexpr int TMODE = TRAIN ? 2 : MODE;             // policy_tail's mode
@@ -474,7 +484,7 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     const int tps = e->H / 32;
     const int64_t N = e->N;
     const int64_t need = (N + 3) / 4;
-    const int wps = (p->HID >= 256) ? 1 : 2;                     // FwdCfg<72, HID>::WPS
+    const int wps = (p->HID >= 256) ? 1 : PPO_FWD_WPS_SMALL;     // FwdCfg<72, HID>::WPS
     const int64_t cap = 256 * wps;
     const unsigned grid = (unsigned)(need < cap ? need : cap);
     const int slots = (int)((N + (int64_t)grid * 4 - 1) / ((int64_t)grid * 4));
