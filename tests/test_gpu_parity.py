@@ -552,6 +552,23 @@ def test_gradient_with_reference_trained_weights(P, orc, golden_dir, fixture, bw
     assert np.array_equal(ro.selected_actions - 1, ref["actions"]) and np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
 
 
+@pytest.mark.parametrize("B", [255, 256, 257, 383, 384, 385, 511, 512, 513])
+def test_gradient_at_the_kernel_switch_points(P, orc, B):
+    """Default kernel selection by minibatch size: 4 waves per state up to 256 states, 2 up to 512, one above; the
+    three-product backward up to 384 tiles, the fused kernel above.  Every size around the switch points gives the float64
+    oracle's gradient (same tolerance), through ppo_train's own path (device index list) as well."""
+    env, pol, ro, ds = _make_dataset(P, orc, 48, 12, 256, seed=91)
+    assert len(ds) == 576
+    sel = np.random.default_rng(B).permutation(len(ds))[:B] + 1
+    lp, le = P.forward_backward(pol, ds, sel, 0.05, 0.01)
+    g = pol.grad()
+    g64, olp, ole = _oracle_grad(orc, pol.params, 256, ro, sel - 1, 0.05, 0.01)
+    assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
+    assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    P.forward_backward(pol, ds, sel, 0.05, 0.01)
+    assert np.array_equal(g, pol.grad()), "bitwise reproducible run to run"
+
+
 def test_gradient_clipped_branch(P, orc):
     """Huge epsilon => never clipped; tiny epsilon with old probabilities scaled => clipped samples carry
     zero policy gradient (only the entropy term remains)."""

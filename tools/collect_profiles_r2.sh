@@ -14,6 +14,7 @@ ls $F/trace_bf16/*/*kernel_stats.csv >/dev/null 2>&1 && cp $(ls -t $F/trace_bf16
 ls $F/trace_h128/*/*kernel_stats.csv >/dev/null 2>&1 && cp $(ls -t $F/trace_h128/*/*kernel_stats.csv | head -1) profiles/r02_rocprof_kernel_stats_hid128.csv
 [ -f $F/disk_stream.json ] && cp $F/disk_stream.json profiles/r02_disk_stream_65536envs.json
 [ -f $F/bench_2ranks_shared_gpu.json ] && cp $F/bench_2ranks_shared_gpu.json profiles/r02_bench_2ranks_shared_gpu.json
+[ -f $F/bench_4ranks_shared_gpu.json ] && cp $F/bench_4ranks_shared_gpu.json profiles/r02_bench_4ranks_shared_gpu.json
 python3 - <<'PY'
 import json, os
 F = "gpurun_out/final2"

@@ -40,5 +40,6 @@ else
     PPO_BENCH_FORCE_DIST=1 timeout -k 10 200 $B --steps 5 --warmup 2 --envs $e > $F/shard_$e.json 2> $F/shard_$e.err || { tail -5 $F/shard_$e.err; exit 1; }
   done
   PPO_BENCH_BACKEND=gloo PPO_BENCH_SHARE_GPU=1 timeout -k 10 300 $B --gpus 2 --steps 2 --warmup 1 > $F/bench_2ranks_shared_gpu.json 2> $F/bench_2ranks.err || { tail -5 $F/bench_2ranks.err; exit 1; }
+  PPO_BENCH_BACKEND=gloo PPO_BENCH_SHARE_GPU=1 timeout -k 10 300 $B --gpus 4 --steps 2 --warmup 1 --envs 1024 > $F/bench_4ranks_shared_gpu.json 2> $F/bench_4ranks.err || { tail -5 $F/bench_4ranks.err; exit 1; }
   ls $F
 fi
