@@ -1,8 +1,7 @@
 // ppo_disk.hip -- out-of-core rollout store (DiskRollouts / DiskDataset: src/rollouts_to_disk.jl:1-171,
 // src/dataset.jl:1-82).  Device -> pinned host copies run on a dedicated copy stream, ordered behind the
-// producing kernels by events, so the PCIe transfer of step t overlaps the kernels of step t+1; writer threads
-// drain the pinned ring into one file (records have a fixed size, so each is a pwrite at its own offset: the
-// page-cache copy of a 5 MB record is what bounds a single writer at 5-8 GB/s, three of them share it).
+// producing kernels by events, so the PCIe transfer of step t overlaps the kernels of step t+1; a writer
+// thread drains the pinned ring into one append-only file.
 //
 // File format (little endian): header {magic "PPOR", u32 version, i64 N, i32 H, i32 F, i32 A, i32 V, i64 T}
 // then T step records  [states][active N u32][actions N i32][p_sel N f32][rewards N f32][done N u8]
@@ -13,7 +12,6 @@
 #include "ppo_internal.h"
 #include <condition_variable>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -32,10 +30,7 @@ struct DiskSink {
     std::vector<hipEvent_t> copied;       // recorded on the copy stream after the D2H of the slot
     hipStream_t copy_stream = nullptr;
     FILE* f = nullptr;
-    std::vector<std::thread> writers;     // PPO_DISK_WRITERS threads (default 3)
-    int64_t claimed = 0;                  // next record a writer thread will take
-    std::vector<int64_t> slot_done;       // slot_done[slot] = 1 + index of the last record of that slot that is in the file
-    size_t data_off = 0;                  // file offset of record 0
+    std::thread writer;
     std::mutex mu;
     std::condition_variable cv;
     int64_t enq = 0, written = 0;         // records handed to the copy stream / written to the file
@@ -80,35 +75,21 @@ static int rm_rf(const std::string& path) {
     return unlink(path.c_str());
 }
 
-static void join_writers(DiskSink* s) {
-    { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
-    s->cv.notify_all();
-    for (auto& t : s->writers) if (t.joinable()) t.join();
-    s->writers.clear();
-}
-
 static void writer_loop(DiskSink* s) {
-    const int fd = fileno(s->f);
     for (;;) {
         int64_t k;
         {
             std::unique_lock<std::mutex> lk(s->mu);
-            s->cv.wait(lk, [&] { return s->stop || s->claimed < s->enq; });
-            if (s->claimed >= s->enq) { if (s->stop) return; continue; }
-            k = s->claimed++;
+            s->cv.wait(lk, [&] { return s->stop || s->written < s->enq; });
+            if (s->written >= s->enq) { if (s->stop) return; continue; }
+            k = s->written;
         }
         const int slot = (int)(k % s->slots);
-        bool ok = hipEventSynchronize(s->copied[slot]) == hipSuccess;                 // D2H of this record landed
-        size_t done = 0;
-        while (ok && done < s->rec_bytes) {
-            const ssize_t w = pwrite(fd, s->pinned[slot] + done, s->rec_bytes - done, (off_t)(s->data_off + (size_t)k * s->rec_bytes + done));
-            if (w <= 0) ok = false; else done += (size_t)w;
-        }
+        if (hipEventSynchronize(s->copied[slot]) != hipSuccess) s->failed = true;     // D2H of this record landed
+        if (!s->failed && fwrite(s->pinned[slot], 1, s->rec_bytes, s->f) != s->rec_bytes) s->failed = true;
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            if (!ok) s->failed = true;
-            s->slot_done[slot] = k + 1;
-            s->written += 1;
+            s->written = k + 1;
         }
         s->cv.notify_all();
     }
@@ -116,7 +97,11 @@ static void writer_loop(DiskSink* s) {
 
 void disk_sink_destroy(DiskSink* s) {
     if (!s) return;
-    join_writers(s);
+    if (s->writer.joinable()) {
+        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+        s->cv.notify_all();
+        s->writer.join();
+    }
     if (s->f) fclose(s->f);
     for (char* p : s->pinned) pinned_put(s->rec_bytes, p);
     for (auto e : s->produced) (void)hipEventDestroy(e);
@@ -171,10 +156,13 @@ int disk_sink_slots(const ppo_rollouts_s* ro) { return ro->sink ? ro->sink->slot
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     DiskSink* s = ro->sink;
     if (!s) return PPO_OK;
-    join_writers(s);                                  // a previous collection: restart the file
+    if (s->writer.joinable()) {                       // a previous collection: restart the file
+        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+        s->cv.notify_all();
+        s->writer.join();
+    }
     if (s->f) { fclose(s->f); s->f = nullptr; }
-    s->enq = s->written = s->claimed = 0; s->stop = false; s->failed = false;
-    s->slot_done.assign((size_t)s->slots, 0);
+    s->enq = s->written = 0; s->stop = false; s->failed = false;
     const size_t rec = record_bytes(ro, ro->compact);           // the storage form is decided per collection
     if (rec != s->rec_bytes) {
         for (char*& p : s->pinned) { pinned_put(s->rec_bytes, p); p = nullptr; }
@@ -187,10 +175,8 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     if (!s->f) { ppo_set_error("DiskRollouts: cannot open " + path); return PPO_ERR_ARG; }
     DiskHeader h;
     memcpy(h.magic, "PPOR", 4); h.version = ro->compact ? 2 : 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.V = ro->V; h.T = T;
-    if (fwrite(&h, sizeof(h), 1, s->f) != 1 || fflush(s->f) != 0) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
-    s->data_off = sizeof(h);
-    static const int nw = [] { const char* v = std::getenv("PPO_DISK_WRITERS"); const int n = v ? atoi(v) : 3; return n < 1 ? 1 : (n > 8 ? 8 : n); }();
-    for (int i = 0; i < nw; ++i) s->writers.emplace_back(writer_loop, s);
+    if (fwrite(&h, sizeof(h), 1, s->f) != 1) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
+    s->writer = std::thread(writer_loop, s);
     return PPO_OK;
 }
 
@@ -200,7 +186,7 @@ int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t) {
     const int slot = (int)(t % s->slots);
     {   // the slot must have been written out before it is overwritten (back-pressure from the disk)
         std::unique_lock<std::mutex> lk(s->mu);
-        s->cv.wait(lk, [&] { return s->failed || t < s->slots || s->slot_done[slot] == t - s->slots + 1; });
+        s->cv.wait(lk, [&] { return s->failed || s->written + s->slots > t; });
     }
     if (s->failed) { ppo_set_error("DiskRollouts: writer failed (disk full?)"); return PPO_ERR_ARG; }
     const size_t N = (size_t)ro->N, sb = state_bytes(ro, ro->compact);
@@ -225,10 +211,11 @@ int32_t disk_sink_finish(ppo_rollouts_s* ro) {
     {   // drain the ring
         std::unique_lock<std::mutex> lk(s->mu);
         s->cv.wait(lk, [&] { return s->failed || s->written >= s->enq; });
+        s->stop = true;
     }
-    join_writers(s);
+    s->cv.notify_all();
+    s->writer.join();
     if (s->failed) { ppo_set_error("DiskRollouts: writer failed"); return PPO_ERR_ARG; }
-    if (fseek(s->f, (long)(s->data_off + (size_t)s->enq * s->rec_bytes), SEEK_SET) != 0) { ppo_set_error("DiskRollouts: seek failed"); return PPO_ERR_ARG; }
     // returns column (the reference rewrites trajectory.csv with the returns at this point)
     const size_t n = (size_t)ro->T * ro->N;
     std::vector<float> ret(n);

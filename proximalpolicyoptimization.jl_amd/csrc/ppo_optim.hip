@@ -23,10 +23,9 @@ static ParamLayout layout_of(const ppo_policy_s* p) {
 __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
                                   float* __restrict__ grad_tail);
 
-// Block = 256 consecutive slab elements (one float4 per lane: 1 KiB per wave access) x 4 slab groups (wave g sums slabs
-// g, g+4, g+8, ... with 8 loads in flight); the four partial sums meet in LDS and are added in a fixed order.  The 87 MB
-// slab walk needs the memory-level parallelism: 4x the waves of a one-thread-per-element layout, and 16-byte instead of
-// 4-byte lane accesses (the order in which every element is summed is unchanged, so are the bits of the result).
+// Block = 64 consecutive slab elements x 4 slab groups (wave g sums slabs g, g+4, g+8, ... with 8 loads in flight);
+// the four partial sums meet in LDS and are added in a fixed order.  4x the waves of a one-thread-per-element
+// layout: the 87 MB slab walk needs the memory-level parallelism (341 blocks of one wave per SIMD did 3.3 TB/s).
 // nwg_w slabs carry weight-gradient partials, nwg_s slabs the small-gradient tails (equal for the fused backward)
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg_w, int nwg_s, ParamLayout L,
                                                      float* __restrict__ grad, const double* __restrict__ terms, int64_t B,
@@ -35,60 +34,46 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
         loss_reduce_block(terms, B, inv_Bg, entropy_weight, grad + L.np);
         return;
     }
-    __shared__ float4 part[4][64];
+    __shared__ float part[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t e0 = ((size_t)blockIdx.x * 64 + el) * 4;          // first of this lane's 4 consecutive elements
+    const size_t e = (size_t)blockIdx.x * 64 + el;
     const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
-    const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;     // a multiple of 4, like nW2 and nW2 + nW1
+    const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     // fixed summation order: 8 interleaved partial sums per slab group, a fixed tree, then the 4 groups in order
-    float4 ps[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) ps[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nwg = (e0 < nW2 + nW1) ? nwg_w : nwg_s;
-    auto add4 = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
-    if (e0 < total) {
+    float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nwg = (e < nW2 + nW1) ? nwg_w : nwg_s;
+    if (e < total) {
         int g = grp;
         for (; g + 28 < nwg; g += 32) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) add4(ps[u], *reinterpret_cast<const float4*>(slabs + (size_t)(g + 4 * u) * slab_stride + e0));
+            for (int u = 0; u < 8; ++u) ps[u] += slabs[(size_t)(g + 4 * u) * slab_stride + e];
         }
-        for (int u = 0; g < nwg; g += 4, ++u) add4(ps[u], *reinterpret_cast<const float4*>(slabs + (size_t)g * slab_stride + e0));
+        for (int u = 0; g < nwg; g += 4, ++u) ps[u] += slabs[(size_t)g * slab_stride + e];
     }
-    auto tree = [&](float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-        return ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-    };
-    part[grp][el] = make_float4(tree(ps[0].x, ps[1].x, ps[2].x, ps[3].x, ps[4].x, ps[5].x, ps[6].x, ps[7].x),
-                                tree(ps[0].y, ps[1].y, ps[2].y, ps[3].y, ps[4].y, ps[5].y, ps[6].y, ps[7].y),
-                                tree(ps[0].z, ps[1].z, ps[2].z, ps[3].z, ps[4].z, ps[5].z, ps[6].z, ps[7].z),
-                                tree(ps[0].w, ps[1].w, ps[2].w, ps[3].w, ps[4].w, ps[5].w, ps[6].w, ps[7].w));
+    part[grp][el] = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
     __syncthreads();
-    if (grp != 0 || e0 >= total) return;
-    const float4 p0 = part[0][el], p1 = part[1][el], p2 = part[2][el], p3 = part[3][el];
-    const float sv[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const size_t e = e0 + c;
-        int64_t canon = -1;
-        if (e < nW2) {
-            const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
-            const int tile = (int)(e >> 10), kt = tile % L.NT, ft = tile / L.NT;
-            const int f = dfeat(ft, r, lane >> 5), k = 32 * kt + (lane & 31);
-            canon = L.offW2 + f + (int64_t)L.HID * k;
-        } else if (e < nW2 + nW1) {
-            const size_t e1 = e - nW2;
-            const int lane = (int)(e1 & 63), r = (int)((e1 >> 6) & 15);
-            const int tile = (int)(e1 >> 10), it = tile % L.NI, ft = tile / L.NI;
-            const int ko = dfeat(ft, r, lane >> 5), i = 32 * it + (lane & 31);
-            if (i < L.F) canon = L.offW1 + ko + (int64_t)L.HID * i;
-        } else {
-            size_t e2 = e - nW2 - nW1;
-            if (e2 < (size_t)L.HID) canon = L.offb1 + (int64_t)e2;
-            else if ((e2 -= L.HID) < (size_t)L.HID) canon = L.offb2 + (int64_t)e2;
-            else if ((e2 -= L.HID) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
-            else canon = L.offb3 + (int64_t)(e2 - (size_t)L.HID * 4);
-        }
-        if (canon >= 0) grad[canon] = sv[c];
+    if (grp != 0 || e >= total) return;
+    const float s = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    int64_t canon = -1;
+    if (e < nW2) {
+        const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
+        const int tile = (int)(e >> 10), kt = tile % L.NT, ft = tile / L.NT;
+        const int f = dfeat(ft, r, lane >> 5), k = 32 * kt + (lane & 31);
+        canon = L.offW2 + f + (int64_t)L.HID * k;
+    } else if (e < nW2 + nW1) {
+        const size_t e1 = e - nW2;
+        const int lane = (int)(e1 & 63), r = (int)((e1 >> 6) & 15);
+        const int tile = (int)(e1 >> 10), it = tile % L.NI, ft = tile / L.NI;
+        const int ko = dfeat(ft, r, lane >> 5), i = 32 * it + (lane & 31);
+        if (i < L.F) canon = L.offW1 + ko + (int64_t)L.HID * i;
+    } else {
+        size_t e2 = e - nW2 - nW1;
+        if (e2 < (size_t)L.HID) canon = L.offb1 + (int64_t)e2;
+        else if ((e2 -= L.HID) < (size_t)L.HID) canon = L.offb2 + (int64_t)e2;
+        else if ((e2 -= L.HID) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
+        else canon = L.offb3 + (int64_t)(e2 - (size_t)L.HID * 4);
     }
+    if (canon >= 0) grad[canon] = s;
 }
 
 // loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global.
@@ -241,7 +226,7 @@ int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double 
     ParamLayout L = layout_of(p);
     const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
     ProfScope ps("k_grad_reduce");
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 255) / 256) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 63) / 64) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
                        slab_floats(p->F, p->HID), p->nwg_bwd, p->nwg_small ? p->nwg_small : p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
                        entropy_weight);
     HIP_TRY(hipGetLastError());
