@@ -219,6 +219,10 @@ int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
  * of one, so a minibatch smaller than the chip's 1024 SIMDs still fills it (logits agree with the one-wave kernel to
  * fp32 rounding: the layer-3 partial sums are added in a different order).  Default 512 (-1 restores it), 0 = never. */
 int32_t ppo_set_fwd_split_max_states(int64_t states);
+/* And for the one-launch rollout: up to `envs` resident envs (Q = 8, fp32) every env is walked by 2 or 4 waves instead of
+ * one.  Unlike the train forward this split is BIT-EXACT (the layer-3 fmaf chain is handed from wave to wave in tile
+ * order), so it changes nothing but the time.  Default 512 (-1 restores it), 0 = never. */
+int32_t ppo_set_rollout_split_max_envs(int64_t envs);
 /* Flux.update!(optimizer, weights, grad)                    src/train.jl:81 */
 int32_t ppo_adam_apply(ppo_adam_t opt, ppo_policy_t pol);
 /* losses of the last forward_backward (after any all-reduce): (ppoloss, entropy_weight*entropyloss)

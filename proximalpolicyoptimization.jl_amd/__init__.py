@@ -116,6 +116,12 @@ def set_fwd_split_max_states(states=None):
     call("ppo_set_fwd_split_max_states", -1 if states is None else int(states))
 
 
+def set_rollout_split_max_envs(envs=None):
+    """One-launch rollouts of up to `envs` envs give every env to 2 or 4 waves (bit-identical results).  None = default
+    (512), 0 = always one wave per env."""
+    call("ppo_set_rollout_split_max_envs", -1 if envs is None else int(envs))
+
+
 def synchronize():
     call("ppo_device_synchronize")
 

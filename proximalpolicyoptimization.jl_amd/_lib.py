@@ -86,6 +86,7 @@ SIGNATURES = {
     "ppo_forward_backward": [H, H, c_i64p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32],
     "ppo_set_bwd_small_max_tiles": [C.c_int64],
     "ppo_set_fwd_split_max_states": [C.c_int64],
+    "ppo_set_rollout_split_max_envs": [C.c_int64],
     "ppo_adam_apply": [H, H],
     "ppo_last_losses": [H, c_f64p, c_f64p],
     "ppo_step_batch": [H, H, H, c_i64p, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p, c_f64p],

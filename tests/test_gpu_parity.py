@@ -315,7 +315,7 @@ def test_policy_any_hidden_width(P, orc, hid):
 
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
-@pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10)])
+@pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10), (300, 5, 256, 4), (300, 6, 128, 5), (1, 30, 256, 12)])
 def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_mode):
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=max_actions, seed=77, global_offset=5)
     pol = P.HipPolicy(72, HID, 2, 4, seed=11)
@@ -340,12 +340,15 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
 
 
-@pytest.fixture(params=[False, True], ids=["per-step", "persistent"])
+@pytest.fixture(params=["per-step", "persistent", "persistent-split"])
 def rollout_mode(request, P):
-    """Both rollout executions: three launches per step, and the whole T-step rollout in one launch (MODE 3)."""
-    P.set_rollout_persistent(request.param)
+    """All rollout executions: three launches per step, the whole T-step rollout in one launch with one wave per env
+    (MODE 3), and the same with 2 / 4 waves per env (what few envs take by default; Q = 8 fp32, one wave otherwise)."""
+    P.set_rollout_persistent(request.param != "per-step")
+    P.set_rollout_split_max_envs(None if request.param == "persistent-split" else 0)
     yield request.param
     P.set_rollout_persistent(None)
+    P.set_rollout_split_max_envs(None)
 
 
 @pytest.fixture(params=[False, True], ids=["expanded", "compact"])
