@@ -198,7 +198,7 @@ int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
 // bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
 struct FwdArgs;
 // one-launch rollout with 2 or 4 waves per env for few envs, bit-identical results (ppo_policy_rollout_split.hip)
-int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V);
+int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V, int env);
 // train forward with 2 or 4 waves per state for small minibatches (ppo_policy_fwd_split.hip)
 int32_t launch_policy_train_fwd_split(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact);
 int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t B, int tps);

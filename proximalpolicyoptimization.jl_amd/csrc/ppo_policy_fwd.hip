@@ -463,6 +463,10 @@ int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uin
     return dispatch_fwd<0>(p, a, B, H / 32);
 }
 
+// rollouts of up to this many envs give every env to 2 or 4 waves; ppo_set_rollout_split_max_envs / PPO_ROLLOUT_SPLIT_MAX_ENVS
+static int64_t g_rollout_split_max_envs = [] { const char* v = std::getenv("PPO_ROLLOUT_SPLIT_MAX_ENVS"); return v ? (int64_t)atoll(v) : (int64_t)512; }();
+extern "C" int32_t ppo_set_rollout_split_max_envs(int64_t envs) { g_rollout_split_max_envs = envs < 0 ? 512 : envs; return PPO_OK; }
+
 int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* states_dev, const uint32_t* active_dev,
                               int32_t* actions_out, float* psel_out, float* full_probs_or_null) {
     FwdArgs a = {};
@@ -472,12 +476,12 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
     a.actions_out = actions_out; a.psel_out = psel_out; a.full_probs = full_probs_or_null; a.err = e->err.p;
     ProfScope ps("k_policy_fwd_rollout");
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_fwd_bf16(p, a, 1, e->N, e->H / 32);
+    if (e->N <= g_rollout_split_max_envs) {   // few envs: 2 or 4 waves per env, same bits
+        const int32_t rs = launch_rollout_split(p, a, e->N, e->H / 32, e->V, 0);
+        if (rs != PPO_ERR_UNSUPPORTED) return rs;
+    }
     return dispatch_fwd<1>(p, a, e->N, e->H / 32);
 }
-
-// rollouts of up to this many envs give every env to 2 or 4 waves; ppo_set_rollout_split_max_envs / PPO_ROLLOUT_SPLIT_MAX_ENVS
-static int64_t g_rollout_split_max_envs = [] { const char* v = std::getenv("PPO_ROLLOUT_SPLIT_MAX_ENVS"); return v ? (int64_t)atoll(v) : (int64_t)512; }();
-extern "C" int32_t ppo_set_rollout_split_max_envs(int64_t envs) { g_rollout_split_max_envs = envs < 0 ? 512 : envs; return PPO_OK; }
 
 // Persistent rollout (MODE 3): T steps of all N envs in one launch.  Returns PPO_ERR_UNSUPPORTED (without setting an
 // error) when the shape is not covered, so the caller falls back to the per-step launches.
@@ -511,7 +515,7 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     ProfScope ps("k_rollout_persistent");
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_rollout_persistent_bf16(p, a, N, tps, e->V);
     if (N <= g_rollout_split_max_envs) {      // few envs: 2 or 4 waves per env, same bits (ppo_policy_rollout_split.hip)
-        const int32_t rs = launch_rollout_split(p, a, N, tps, e->V);
+        const int32_t rs = launch_rollout_split(p, a, N, tps, e->V, 1);
         if (rs != PPO_ERR_UNSUPPORTED) return rs;
         a.env_slots = slots;
     }

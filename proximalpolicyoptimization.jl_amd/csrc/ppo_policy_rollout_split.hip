@@ -13,7 +13,10 @@
 #include "ppo_policy_tail.h"
 #include "ppo_env_device.h"
 
-template <int F, int HID, int S>
+// ENV = 1: the persistent rollout (env state in LDS, T steps); ENV = 0: one step of the per-step form (k_policy_fwd MODE 1:
+// rows, active-quad word and tick come from global arrays, the env is stepped by k_env_step afterwards) -- what
+// collect_rollouts!(.., num_episodes, ..) and the evaluator run, usually on few envs
+template <int F, int HID, int S, int ENV>
 __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
     constexpr int NT = HID / 32, NTS = NT / S, G = 4 / S;
     constexpr int S41 = F / 8, S42 = NT * 4, XB = F / 2, XW = XB / 4;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
     EnvConst ec;
     ec.Q = a.envQ; ec.V = a.envV; ec.max_actions = a.env_max_actions; ec.no_action_reward = a.env_nar; ec.k0 = a.k0; ec.k1 = a.k1;
     const int64_t gid = (int64_t)blockIdx.x * G + grp, ngroups = (int64_t)gridDim.x * G;
-    if (sw == S - 1) {                                           // the tail wave owns the group's env slots
+    if (ENV && sw == S - 1) {                                    // the tail wave owns the group's env slots
         int slot = 0;
         for (int64_t n = gid; n < a.B; n += ngroups, ++slot) {
             const EnvRefLds r = slot_ref(slot);
@@ -57,29 +60,38 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
             }
         }
     }
-    uint32_t tmpl_regs[9];
-    {
+    uint32_t tmpl_regs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ENV) {
         const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
 #pragma unroll
         for (int k = 0; k < 9; ++k) tmpl_regs[k] = tp[k];
     }
     __syncthreads();
     const int64_t iters = (a.B + ngroups - 1) / ngroups;        // env slots per group: the same loop bounds for every wave
-    for (int64_t tt = 0; tt < a.T; ++tt) {
+    const int64_t t_steps = ENV ? a.T : 1;
+    for (int64_t tt = 0; tt < t_steps; ++tt) {
         for (int64_t it = 0; it < iters; ++it) {
             const int64_t state = it * ngroups + gid;
             const bool live = state < a.B;                         // uniform within the group
-            const EnvRefLds er = slot_ref((int)it);
-            const int64_t out_index = tt * a.B + state;
+            EnvRefLds er = {};
+            if (ENV) er = slot_ref((int)it);
+            const int64_t out_index = ENV ? tt * a.B + state : state;
             int lane_o = lane, half_o = h;
             asm volatile("" : "+v"(lane_o), "+v"(half_o));         // per-step opaque offsets (see k_policy_fwd)
             uint32_t act = 0u, tick_val = 0u;
             if (live) {
-                act = *er.active; tick_val = *er.tick;
-                // ---- state(env): every wave of the group needs the rows (layer-1 B operands); the tail wave records them
                 uint32_t ob[9];
-                env_observe_lane(er, tmpl_regs, j, h, ob);
-                if (sw == S - 1) {
+                if (ENV) {
+                    act = *er.active; tick_val = *er.tick;
+                    // ---- state(env): every wave of the group needs the rows (layer-1 B operands); the tail wave records them
+                    env_observe_lane(er, tmpl_regs, j, h, ob);
+                } else {
+                    act = a.active[state]; tick_val = a.tick[state];
+                    const uint32_t* xr = reinterpret_cast<const uint32_t*>(a.states + (size_t)state * 32 * F + (size_t)j * F + (size_t)h * XB);
+#pragma unroll
+                    for (int k = 0; k < XW; ++k) ob[k] = xr[k];
+                }
+                if (ENV && sw == S - 1) {
                     if (a.states_out) {
                         uint32_t* so = reinterpret_cast<uint32_t*>(a.states_out + (size_t)out_index * 32 * F + (size_t)j * F + (size_t)h * XB);
 #pragma unroll
@@ -197,7 +209,8 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
                 l[0][1] = (p1 + __shfl_xor(p1, 32)) + a.b3[1];
                 l[0][2] = (p2 + __shfl_xor(p2, 32)) + a.b3[2];
                 l[0][3] = (p3 + __shfl_xor(p3, 32)) + a.b3[3];
-                const int sampled = policy_tail<3, 1, false>(a, state, state, act, l, lane, j, h, tick_val, out_index);
+                const int sampled = policy_tail<(ENV ? 3 : 1), 1, false>(a, state, state, act, l, lane, j, h, tick_val, out_index);
+                if (ENV) {
                 asm volatile("" ::: "memory");
                 float rew; uint8_t dn;
                 const int errf = env_step_wave32(ec, er, sampled, lane, rew, dn);
@@ -209,11 +222,12 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
                 }
                 if (dn) env_reset_wave32(ec, er, (uint32_t)(a.global_offset + state), lane);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
             __syncthreads();                                        // the other waves see the stepped env; sH / sP are free again
         }
     }
-    if (sw == S - 1) {                                              // env state back to the [N] arrays
+    if (ENV && sw == S - 1) {                                       // env state back to the [N] arrays
         int slot2 = 0;
         for (int64_t n = gid; n < a.B; n += ngroups, ++slot2) {
             const EnvRefLds r = slot_ref(slot2);
@@ -226,32 +240,33 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
     }
 }
 
-template <int HID>
+template <int HID, int ENV>
 static int32_t launch_rs(FwdArgs& a, int64_t N, int V) {
     constexpr int NT = HID / 32;
     const int S = (N <= 256) ? 4 : 2, G = 4 / S;
     const int64_t need = (N + G - 1) / G;
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
-    const int slots = (int)((N + (int64_t)grid * G - 1) / ((int64_t)grid * G));
+    const int slots = ENV ? (int)((N + (int64_t)grid * G - 1) / ((int64_t)grid * G)) : 0;
     a.env_slots = slots;
     const size_t lds = (size_t)G * NT * 4096 + (size_t)G * slots * (2 * V + 32);
     if (lds > 140 * 1024) return PPO_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 4, ENV>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 2, ENV>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         attr_set = true;
     }
-    if (S == 4) hipLaunchKernelGGL((k_rollout_split<72, HID, 4>), dim3(grid), dim3(256), lds, ppo_stream(), a);
-    else hipLaunchKernelGGL((k_rollout_split<72, HID, 2>), dim3(grid), dim3(256), lds, ppo_stream(), a);
+    if (S == 4) hipLaunchKernelGGL((k_rollout_split<72, HID, 4, ENV>), dim3(grid), dim3(256), lds, ppo_stream(), a);
+    else hipLaunchKernelGGL((k_rollout_split<72, HID, 2, ENV>), dim3(grid), dim3(256), lds, ppo_stream(), a);
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }
 
-// `a` comes filled from launch_policy_rollout_persistent.  PPO_ERR_UNSUPPORTED (no error text): shape not covered.
-int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V) {
+// `a` comes filled from launch_policy_rollout_persistent (env = 1) or launch_policy_rollout (env = 0, one step).
+// PPO_ERR_UNSUPPORTED (no error text): shape not covered.
+int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V, int env) {
     if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || tps != 1 || V != 32) return PPO_ERR_UNSUPPORTED;
-    if (p->HID == 256) return launch_rs<256>(a, N, V);
-    if (p->HID == 128) return launch_rs<128>(a, N, V);
+    if (p->HID == 256) return env ? launch_rs<256, 1>(a, N, V) : launch_rs<256, 0>(a, N, V);
+    if (p->HID == 128) return env ? launch_rs<128, 1>(a, N, V) : launch_rs<128, 0>(a, N, V);
     return PPO_ERR_UNSUPPORTED;
 }

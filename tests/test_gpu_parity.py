@@ -340,12 +340,12 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
 
 
-@pytest.fixture(params=["per-step", "persistent", "persistent-split"])
+@pytest.fixture(params=["per-step", "per-step-split", "persistent", "persistent-split"])
 def rollout_mode(request, P):
-    """All rollout executions: three launches per step, the whole T-step rollout in one launch with one wave per env
-    (MODE 3), and the same with 2 / 4 waves per env (what few envs take by default; Q = 8 fp32, one wave otherwise)."""
-    P.set_rollout_persistent(request.param != "per-step")
-    P.set_rollout_split_max_envs(None if request.param == "persistent-split" else 0)
+    """All rollout executions: three launches per step and the whole T-step rollout in one launch (MODE 3), each with one
+    wave per env and with 2 / 4 waves per env (what few envs take by default; Q = 8 fp32, one wave otherwise)."""
+    P.set_rollout_persistent(request.param not in ("per-step", "per-step-split"))
+    P.set_rollout_split_max_envs(None if request.param.endswith("split") else 0)
     yield request.param
     P.set_rollout_persistent(None)
     P.set_rollout_split_max_envs(None)
