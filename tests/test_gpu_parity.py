@@ -316,7 +316,8 @@ def test_policy_any_hidden_width(P, orc, hid):
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
 @pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10), (300, 5, 256, 4), (300, 6, 128, 5), (1, 30, 256, 12)])
-def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_mode):
+def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode):
+    _storage(P, (N + T) % 2)
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=max_actions, seed=77, global_offset=5)
     pol = P.HipPolicy(72, HID, 2, 4, seed=11)
     ro = P.BufferRollouts()
@@ -338,6 +339,7 @@ def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode, storage_
     P.collect_rollouts_steps_(ro, env, pol, 8, 1.0)
     ref2 = orc.collect_rollouts_tn(oenv, pol.params, HID, 8, mode_dev=True)
     assert np.array_equal(ro.selected_actions - 1, ref2["actions"])
+    P.set_rollout_compact(None)
 
 
 @pytest.fixture(params=["per-step", "per-step-split", "persistent", "persistent-split"])
@@ -349,6 +351,19 @@ def rollout_mode(request, P):
     yield request.param
     P.set_rollout_persistent(None)
     P.set_rollout_split_max_envs(None)
+
+
+@pytest.fixture(params=["per-step", "persistent"])
+def rollout_mode2(request, P):
+    """Per-step launches vs the one-launch rollout, for shapes the 2 / 4-waves-per-env kernels do not cover (Q = 32)."""
+    P.set_rollout_persistent(request.param == "persistent")
+    yield request.param
+    P.set_rollout_persistent(None)
+
+
+def _storage(P, compact):
+    """Pick a state-storage form inside a test whose parameters already multiply (undone by the caller)."""
+    P.set_rollout_compact(bool(compact))
 
 
 @pytest.fixture(params=[False, True], ids=["expanded", "compact"])
@@ -373,10 +388,11 @@ def bwd_form(request, P):
 
 
 @pytest.mark.parametrize("case", range(10))
-def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode, storage_mode):
+def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode):
     """Randomised shapes / seeds / horizons / global offsets: whole rollouts stay bit-identical to the device-order
     oracle (states, masks, sampled actions, probabilities, rewards, done flags, returns in both discount types)."""
     rng = np.random.default_rng(1000 + case)
+    _storage(P, case % 2)                               # odd cases keep env snapshots, even ones the observation rows
     N = int(rng.integers(1, 70))
     T = int(rng.integers(1, 40))
     HID = int(rng.choice([128, 256]))
@@ -401,10 +417,11 @@ def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode, storage_mode):
     assert np.array_equal(ro.rewards, orc.compute_returns_tn(ref["rewards"], ref["done"], float(gamma),
                                                              isinstance(gamma, np.float32)))
     assert env.error_flags() & ~32 == 0
+    P.set_rollout_compact(None)
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 31, 33, 255, 257])
-def test_gradient_ragged_batch_sizes(P, orc, B, storage_mode, bwd_form):
+def test_gradient_ragged_batch_sizes(P, orc, B, bwd_form):
     """Minibatches that do not fill the persistent grid (B = 1 ... 257 tiles on 256 workgroups) and repeat samples."""
     env, pol, ro, ds = _make_dataset(P, orc, 30, 10, 256, seed=77)      # 300 samples
     rng = np.random.default_rng(B)
@@ -634,7 +651,7 @@ def test_step_batch_adam_bitexact(P, orc):
         P.get_optimizer_learning_rate(P.Adam(1e-4))          # a bare Adam is not iterable (src/train.jl:155-158)
 
 
-def test_ppo_train_epochs_with_explicit_perm(P, orc, storage_mode):
+def test_ppo_train_epochs_with_explicit_perm(P, orc):
     """ppo_train! (src/train.jl:86-153) with explicitly supplied permutations (stand-in for randperm):
     per-epoch mean losses and final parameters vs the oracle loop (f64 grad -> f32 -> oracle Adam)."""
     env, pol, ro, ds = _make_dataset(P, orc, 12, 10, 128, seed=21)
@@ -741,7 +758,7 @@ def test_policy_forward_q32(P, orc):
 
 
 @pytest.mark.parametrize("HID", [128, 256])
-def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode, storage_mode, bwd_form):
+def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode2, storage_mode):
     """square_mesh-sized action space (Q=32 quads, 512 masked actions), variable-length episodes."""
     N, T, max_actions = 12, 20, 9
     env = P.HipVecEnv(num_envs=N, Q=32, max_actions=max_actions, seed=31)
@@ -767,12 +784,18 @@ def test_rollout_and_gradient_q32(P, orc, HID, rollout_mode, storage_mode, bwd_f
                                             ro.rewards.reshape(-1)[sel - 1], 0.05, 0.01)
     assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
     assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
+    P.set_bwd_small_max_tiles(0)                           # the same minibatch through the fused backward (120 tiles)
+    try:
+        P.forward_backward(pol, ds, sel, 0.05, 0.01)
+    finally:
+        P.set_bwd_small_max_tiles(None)
+    assert np.abs(pol.grad() - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
     opt = P.Optimiser(P.Adam(1e-4))
     ph, eh, _ = P.ppo_train_(pol, opt, ds, 0.05, 64, 1, 0.01, seed=3, verbose=False)
     assert np.isfinite(ph[0]) and np.isfinite(eh[0])
 
 
-def test_config4_size_properties(P, orc, rollout_mode):
+def test_config4_size_properties(P, orc, rollout_mode2):
     """BASELINE config 4 size: 8192 envs, Q=32 (A=512), masked actions, variable-length episodes; both rollout
     executions (per-step launches and the one-launch persistent rollout)."""
     N, T = 8192, 16
