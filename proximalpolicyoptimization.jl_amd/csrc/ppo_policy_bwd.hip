@@ -65,6 +65,12 @@ struct BwdArgs {
 #ifndef PPO_BWD_XMODE
 #define PPO_BWD_XMODE 0
 #endif
+// which state dword a thread stages: 1 = lane -> tile row, so the 32 lanes of a transposing LDS write land in 32 banks
+// (the global load is then a 72-byte-stride gather inside a 2.3 KB, cache-resident tile); 0 = linear (coalesced load,
+// 4.5-way bank conflicts on the writes: the 6 % SQ_LDS_BANK_CONFLICT of round 1)
+#ifndef PPO_BWD_XROWLANE
+#define PPO_BWD_XROWLANE 1
+#endif
 template <int F, int HID>
 struct BwdCfg {
     static constexpr int XMODE = (F == 72) ? ((HID == 128 && PPO_BWD_XMODE == 0) ? 1 : PPO_BWD_XMODE) : 0;   // HID = 128 needs an int8 form (LDS)
@@ -183,8 +189,13 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
-            xd[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+            const unsigned u = (unsigned)tid + (unsigned)i * NTHR;
+#if PPO_BWD_XROWLANE
+            const unsigned d = (u & 31u) * (unsigned)(F / 4) + (u >> 5);      // lane -> row, 32-lane group -> one feature dword
+#else
+            const unsigned d = u;
+#endif
+            xd[i] = u < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
         }
     };
     if ((int64_t)blockIdx.x < a.B)
@@ -242,9 +253,13 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         }
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const int d = tid + i * NTHR;                         // dword d = row*(F/4) + c : features 4c..4c+3
+            const int d = tid + i * NTHR;                         // dword row*(F/4) + c : features 4c..4c+3 of a row
             if (d < XDW) {
-                const int row = d / (F / 4), c = d % (F / 4);
+#if PPO_BWD_XROWLANE
+                const int row = d & 31, c = d >> 5;               // the 32 lanes of an LDS write hold 32 rows of ONE feature dword:
+#else                                                             // banks (16c + row) mod 64 are all different
+                const int row = d / (F / 4), c = d % (F / 4);     // consecutive lanes = consecutive c: c and c + 4 collide (4.5-way)
+#endif
                 if (XN8 && 4 * c < NIM * 32) { *reinterpret_cast<uint32_t*>(sXb + row * XS + 4 * c) = xd[i]; continue; }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
