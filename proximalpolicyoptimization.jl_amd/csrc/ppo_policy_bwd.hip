@@ -71,6 +71,12 @@ struct BwdArgs {
 #ifndef PPO_BWD_XROWLANE
 #define PPO_BWD_XROWLANE 1
 #endif
+// dH2 = W3^T dY of the wave's feature tile: 1 = two MFMAs (k = the 4 outputs) whose accumulator IS the lane-is-row
+// fragment the phase needs; 0 = 64 FMAs + 16 LDS reads of W3 per lane (round-1 form).  Only where the 16 extra live
+// registers fit: at HID = 256 the kernel sits at 256 VGPRs and the MFMA form spills 10 of them.
+#ifndef PPO_BWD_DH2_MFMA
+#define PPO_BWD_DH2_MFMA 1
+#endif
 template <int F, int HID>
 struct BwdCfg {
     static constexpr int XMODE = (F == 72) ? ((HID == 128 && PPO_BWD_XMODE == 0) ? 1 : PPO_BWD_XMODE) : 0;   // HID = 128 needs an int8 form (LDS)
@@ -142,6 +148,9 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     }
     __syncthreads();
 
+    constexpr bool DH2M = PPO_BWD_DH2_MFMA && HID <= 128;
+    // A operand of dH2^T[f, row] = sum_o W3[o, f] dY[row, o] for feature f = 32w + j: k-step s, lane half h -> output o = 2s + h
+    const float w3a0 = DH2M ? sW3[(32 * w + j) * 4 + h] : 0.0f, w3a1 = DH2M ? sW3[(32 * w + j) * 4 + 2 + h] : 0.0f;
     const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
     const unsigned lo16 = (unsigned)lane * 16u;
     const unsigned fb = (unsigned)(32 * w + 4 * h);
@@ -236,16 +245,26 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
         // feature of register r: 32w + 4h + (r&3) + 8(r>>2)  ->  one base per array + compile-time offsets
         // (the offsets fold into the ds_* immediate field; no per-element address registers)
+        f32x16 dh2;
+        if constexpr (DH2M) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh2[r] = 0.0f;
+            dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a0, h ? dy.y : dy.x, dh2, 0, 0, 0);     // register r = 4q + e <-> feature e + 8q (+ 4h)
+            dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a1, h ? dy.w : dy.z, dh2, 0, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
             const float h1v[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                constexpr int dummy = 0; (void)dummy;
                 const int fo = e + 8 * q;                          // feature offset inside the tile
-                const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
-                const float dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
+                float dh;
+                if constexpr (DH2M) dh = dh2[4 * q + e];
+                else {
+                    const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
+                    dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
+                }
                 z2b[fo * LD] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
                 h2b[fo * LD] = h2v[e];
                 h1b[fo * LD] = h1v[e];
