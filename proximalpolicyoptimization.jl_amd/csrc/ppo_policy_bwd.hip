@@ -77,6 +77,9 @@ struct BwdArgs {
 #ifndef PPO_BWD_DH2_MFMA
 #define PPO_BWD_DH2_MFMA 1
 #endif
+#ifndef PPO_BWD_DH2_MFMA_MAX_HID
+#define PPO_BWD_DH2_MFMA_MAX_HID 256
+#endif
 template <int F, int HID>
 struct BwdCfg {
     static constexpr int XMODE = (F == 72) ? ((HID == 128 && PPO_BWD_XMODE == 0) ? 1 : PPO_BWD_XMODE) : 0;   // HID = 128 needs an int8 form (LDS)
@@ -148,9 +151,8 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     }
     __syncthreads();
 
-    constexpr bool DH2M = PPO_BWD_DH2_MFMA && HID <= 128;
-    // A operand of dH2^T[f, row] = sum_o W3[o, f] dY[row, o] for feature f = 32w + j: k-step s, lane half h -> output o = 2s + h
-    const float w3a0 = DH2M ? sW3[(32 * w + j) * 4 + h] : 0.0f, w3a1 = DH2M ? sW3[(32 * w + j) * 4 + 2 + h] : 0.0f;
+    constexpr bool DH2M = PPO_BWD_DH2_MFMA && HID <= PPO_BWD_DH2_MFMA_MAX_HID;
+
     const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
     const unsigned lo16 = (unsigned)lane * 16u;
     const unsigned fb = (unsigned)(32 * w + 4 * h);
@@ -231,9 +233,21 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         // registers at the top of phase D of the previous tile (v1/dy/xd), the layer-2 fragments came by LDS-DMA.
         float4 v2[4];
         {
-            // wait for everything this wave has in flight (its DMA is the oldest), read the raw 4 KiB of layer-2
-            // fragments out of the slice, and only then overwrite the slice with the transposed tile below
+            // wait for everything this wave has in flight (its DMA is the oldest)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (DH2M) {
+                // the layer-1 fragments go to their transposed places FIRST: their 16 registers are free again before the
+                // dH2 accumulator and the layer-2 fragments come alive (the kernel sits at the 256-register budget)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float h1v[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h1b[(e + 8 * q) * LD] = h1v[e];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // read the raw 4 KiB of layer-2 fragments out of the slice, and only then overwrite the slice with the
+            // transposed tile below
 #pragma unroll
             for (int q = 0; q < 4; ++q) v2[q] = *reinterpret_cast<const float4*>(h2slice + q * 256 + lane * 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -249,6 +263,9 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         if constexpr (DH2M) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dh2[r] = 0.0f;
+            // A operand of dH2^T[f, row] = sum_o W3[o, f] dY[row, o] for feature f = 32w + j: k-step s, lane half h -> output
+            // o = 2s + h (two LDS dwords per tile: not worth two registers across the whole tile loop)
+            const float w3a0 = sW3[(32 * w + j) * 4 + h], w3a1 = sW3[(32 * w + j) * 4 + 2 + h];
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a0, h ? dy.y : dy.x, dh2, 0, 0, 0);     // register r = 4q + e <-> feature e + 8q (+ 4h)
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a1, h ? dy.w : dy.z, dh2, 0, 0, 0);
         }
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
                 }
                 z2b[fo * LD] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
                 h2b[fo * LD] = h2v[e];
-                h1b[fo * LD] = h1v[e];
+                if constexpr (!DH2M) h1b[fo * LD] = h1v[e];
             }
         }
 #pragma unroll
