@@ -76,6 +76,14 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
         const float4 dy = ndy;
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
         float4* const zo = a.dz2f + ((size_t)tile * NT + w) * 4 * 64 + lane;
+        // dH2^T[f, row] = sum_o W3[o, f] dY[row, o] of this wave's feature tile as two MFMAs (k = the 4 outputs): the
+        // accumulator is the lane-is-row fragment, register 4q + e <-> feature e + 8q (+ 4h) (see k_policy_bwd)
+        f32x16 dh2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh2[r] = 0.0f;
+        dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW3[(32 * w + j) * 4 + h], h ? dy.y : dy.x, dh2, 0, 0, 0);
+        dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW3[(32 * w + j) * 4 + 2 + h], h ? dy.w : dy.z, dh2, 0, 0, 0);
+        (void)w3b;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
@@ -83,8 +91,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = e + 8 * q;
-                const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
-                const float dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
+                const float dh = dh2[4 * q + e];
                 z[e] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
                 z2b[fo * LD] = z[e];
                 h2b[fo * LD] = h2v[e];
