@@ -315,7 +315,7 @@ def test_policy_any_hidden_width(P, orc, hid):
 
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
-@pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10), (300, 3, 256, 4), (300, 6, 128, 5), (1, 30, 256, 12)])
+@pytest.mark.parametrize("N,T,HID,max_actions", [(64, 40, 128, 16), (8, 24, 256, 10), (300, 5, 256, 4), (300, 6, 128, 5), (1, 30, 256, 12)])
 def test_rollout_bitexact(P, orc, N, T, HID, max_actions, rollout_mode):
     _storage(P, (N + T) % 2)
     env = P.HipVecEnv(num_envs=N, Q=8, max_actions=max_actions, seed=77, global_offset=5)
