@@ -74,6 +74,18 @@ struct ppo_env_s {
     DevBuf<int8_t> tmpl;               // [H][36] template vertex ids (env_template), -1 = missing: looked up by k_env_observe
 };
 
+// k-slot order of the packed W2^T fragments (backward: dH1^T = W2^T dZ2^T).  Row form: component e of fragment group g,
+// lane half hh <-> contraction feature 8g + 4hh + e, so the B operands of four MFMAs are ONE 16-byte LDS read of a
+// row-major dZ2 tile; else feature 8g + 2e + hh against a feature-major tile, one ds_read_b32 per MFMA (round-1 form).
+// Measured (gpurun_out/r2x, alternating): HID = 128 backward 0.1170 -> 0.1156 ms with the row form; at HID = 256 it is
+// 0.3 % SLOWER (0.3423 -> 0.3432: LDS instructions beside an fp32 MFMA are not what that kernel waits for, and phase C
+// then needs four 4-byte reads per A operand), so the row form is used up to this width only.  Shared by ppo_optim.hip
+// (packing), ppo_policy_bwd.hip and ppo_policy_bwd_small.hip.
+#ifndef PPO_BWD_Z2ROW_MAX_HID
+#define PPO_BWD_Z2ROW_MAX_HID 128
+#endif
+#define PPO_BWD_Z2ROW_AT(HID) ((HID) <= PPO_BWD_Z2ROW_MAX_HID)
+
 struct ppo_policy_s {
     int32_t F, HID, L, OUT;            // HID: the width the kernels run (128 or 256)
     int32_t hid_user = 0;              // hidden_channels the caller asked for (<= HID): the missing units are zero-padded

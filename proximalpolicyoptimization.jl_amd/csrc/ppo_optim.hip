@@ -139,9 +139,10 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             const int s = 16 * (k >> 5) + r;
             P.w2p[((size_t)((f >> 5) * (HID / 8) + (s >> 2)) * 64 + (f & 31) + 32 * hh) * 4 + (s & 3)] = x;
         }
-        {   // backward A operand (W2^T): out k, contraction f = 2s + hh
-            const int s = f >> 1, hh = f & 1;
-            P.w2tp[((size_t)((k >> 5) * (HID / 8) + (s >> 2)) * 64 + (k & 31) + 32 * hh) * 4 + (s & 3)] = x;
+        {   // backward A operand (W2^T): out k, contraction slot (group g, component e, lane half hh) of feature f
+            const bool zrow = PPO_BWD_Z2ROW_AT(HID);
+            const int g = f >> 3, hh = zrow ? (f >> 2) & 1 : f & 1, e = zrow ? f & 3 : (f >> 1) & 3;   // f = 8g + 4hh + e  |  8g + 2e + hh
+            P.w2tp[((size_t)((k >> 5) * (HID / 8) + g) * 64 + (k & 31) + 32 * hh) * 4 + e] = x;
         }
         if (P.w2b) {
             const uint16_t xb = to_bf16(x);

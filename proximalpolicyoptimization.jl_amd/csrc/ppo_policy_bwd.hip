@@ -37,6 +37,10 @@
 #define PPO_BWD_KG 2
 #endif
 
+// two fp32 FMAs per vector instruction (v_pk_fma_f32; each element is the same IEEE fma as fmaf)
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct BwdArgs {
     unsigned long long* stamps;   // diagnostic build only (-DPPO_BWD_STAMP): [nwg][2 waves][6 phases]
 
@@ -80,6 +84,12 @@ struct BwdArgs {
 #ifndef PPO_BWD_DH2_MFMA_MAX_HID
 #define PPO_BWD_DH2_MFMA_MAX_HID 256
 #endif
+// workgroup barrier between phases B and C/D (round-1 form; no data flow needs it, see the loop) for hidden widths below
+// this one.  Measured (gpurun_out/r2v): HID = 256 0.3430 -> 0.3420 ms without it, HID = 128 0.1165 -> 0.1178 ms (two
+// workgroups share a CU there and the barrier keeps their MFMA phases apart).
+#ifndef PPO_BWD_BAR2_BELOW_HID
+#define PPO_BWD_BAR2_BELOW_HID 256
+#endif
 template <int F, int HID>
 struct BwdCfg {
     static constexpr int XMODE = (F == 72) ? ((HID == 128 && PPO_BWD_XMODE == 0) ? 1 : PPO_BWD_XMODE) : 0;   // HID = 128 needs an int8 form (LDS)
@@ -107,14 +117,18 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     // ~6 ns whether it returns 4 or 16 bytes per lane (tools/microbench/mfma_f32_lds_overlap.hip), and these kernels
     // issued one ds_read_b32 per MFMA.
     constexpr int LD = PPO_BWD_LD;
-    constexpr int XDW = 32 * F / 4;             // dwords of one state
-    constexpr int XPD = (XDW + NTHR - 1) / NTHR;  // state dwords staged per thread
+    static_assert(F % 8 == 0, "state rows are staged in 8-byte units");
+    constexpr int XQW = 32 * F / 8;             // 8-byte units of one state (F = 72, 512 threads: ONE pass, 288 threads busy;
+    constexpr int XPD = (XQW + NTHR - 1) / NTHR;  //   as dwords it was a full pass plus a 64-thread one with its own addresses)
     constexpr int PF = (HID >= 256) ? 2 : 4;    // W2^T fragment groups per register set (two sets, ping-ponged)
     constexpr int S4 = HID / 8;                 // fragment groups of one W2^T tile
     static_assert(S4 % (2 * PF) == 0 && NTHR >= 256 && NTHR >= HID, "shape");
+    // dZ2 row-major [32 rows][RS]: RS = HID + 4 puts the 16 lanes of a 16-byte access (rows j .. j+15) on 64 different banks
+    constexpr bool Z2R = PPO_BWD_Z2ROW_AT(HID);
+    constexpr int RS = HID + 4, Z2SZ = Z2R ? 32 * RS : HID * LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sZ2 = smem;                          // [HID][33]  dZ2^T
-    float* sH1 = sZ2 + HID * LD;                // [HID][33]  H1^T
+    float* sZ2 = smem;                          // Z2R: dZ2 [32][RS]; else [HID][LD] dZ2^T
+    float* sH1 = sZ2 + Z2SZ;                    // [HID][LD]  H1^T
     float* sH2 = sH1 + HID * LD;                // [HID][33]  H2^T
     float* sZ1 = sH2 + HID * LD;                // [HID][33]  dZ1^T
     float* sX = sZ1 + HID * LD;                 // [NIM*32][33]  X^T (float), MFMA part  (XI8: int8 [NIM*32][LD bytes])
@@ -132,9 +146,9 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
 
     f32x16 accW2[NT];
     f32x16 accW1[NIM];
-    float tl[FT > 0 ? FT : 1];                  // dW1[k = 32w+j][NIM*32 + c], rows of this lane half
+    pk2 tl2[FT > 0 ? FT / 2 : 1];               // dW1[k = 32w+j][NIM*32 + c], rows of this lane half (pairs: v_pk_fma_f32)
 #pragma unroll
-    for (int c = 0; c < (FT > 0 ? FT : 1); ++c) tl[c] = 0.0f;
+    for (int c = 0; c < (FT > 0 ? FT / 2 : 1); ++c) tl2[c] = pk2{0.0f, 0.0f};
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     if ((int64_t)blockIdx.x < a.B) dma_next_act2(blockIdx.x);
 
     float4 v1[4], dy;
-    uint32_t xd[XPD];
+    uint2 xd[XPD];
     auto issue_tile_loads = [&](int64_t t, int sidx) {      // sidx: transition id of tile t's state (wave-uniform)
         // scalar (SGPR) base + 32-bit per-lane byte offset -> saddr-form loads, no per-lane 64-bit pointers
         const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)t * NT + w) * 4 * 64);
@@ -202,11 +216,11 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         for (int i = 0; i < XPD; ++i) {
             const unsigned u = (unsigned)tid + (unsigned)i * NTHR;
 #if PPO_BWD_XROWLANE
-            const unsigned d = (u & 31u) * (unsigned)(F / 4) + (u >> 5);      // lane -> row, 32-lane group -> one feature dword
+            const unsigned d = (u & 31u) * (unsigned)(F / 8) + (u >> 5);      // lane -> row, 32-lane group -> one 8-feature unit
 #else
             const unsigned d = u;
 #endif
-            xd[i] = u < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+            xd[i] = u < (unsigned)XQW ? *reinterpret_cast<const uint2*>(xs + d * 8u) : make_uint2(0u, 0u);
         }
     };
     if ((int64_t)blockIdx.x < a.B)
@@ -269,10 +283,12 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a0, h ? dy.y : dy.x, dh2, 0, 0, 0);     // register r = 4q + e <-> feature e + 8q (+ 4h)
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a1, h ? dy.w : dy.z, dh2, 0, 0, 0);
         }
+        float* const z2r = sZ2 + j * RS + fb;                      // Z2R: this lane's row, features 32w + 4h + 8q .. +3
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
             const float h1v[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+            float z[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = e + 8 * q;                          // feature offset inside the tile
@@ -282,28 +298,37 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
                     const float4 ww = *reinterpret_cast<const float4*>(w3b + fo * 4);
                     dh = fmaf(ww.w, dy.w, fmaf(ww.z, dy.z, fmaf(ww.y, dy.y, ww.x * dy.x)));
                 }
-                z2b[fo * LD] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                z[e] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                if constexpr (!Z2R) z2b[fo * LD] = z[e];
                 h2b[fo * LD] = h2v[e];
                 if constexpr (!DH2M) h1b[fo * LD] = h1v[e];
             }
+            if constexpr (Z2R) *reinterpret_cast<float4*>(z2r + 8 * q) = make_float4(z[0], z[1], z[2], z[3]);
         }
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const int d = tid + i * NTHR;                         // dword row*(F/4) + c : features 4c..4c+3 of a row
-            if (d < XDW) {
+            const int d = tid + i * NTHR;                         // unit row*(F/8) + c : features 8c..8c+7 of a row
+            if (d < XQW) {
 #if PPO_BWD_XROWLANE
-                const int row = d & 31, c = d >> 5;               // the 32 lanes of an LDS write hold 32 rows of ONE feature dword:
-#else                                                             // banks (16c + row) mod 64 are all different
-                const int row = d / (F / 4), c = d % (F / 4);     // consecutive lanes = consecutive c: c and c + 4 collide (4.5-way)
+                const int row = d & 31, c = d >> 5;               // the 32 lanes of an LDS write hold 32 rows of ONE feature:
+#else                                                             // banks (LD*f + row) mod 64 are all different
+                const int row = d / (F / 8), c = d % (F / 8);     // consecutive lanes = consecutive c: bank conflicts on the writes
 #endif
-                if (XN8 && 4 * c < NIM * 32) { *reinterpret_cast<uint32_t*>(sXb + row * XS + 4 * c) = xd[i]; continue; }
+                const uint32_t xw[2] = {xd[i].x, xd[i].y};
+                if (8 * c < NIM * 32) {
+                    if (XN8) { *reinterpret_cast<uint2*>(sXb + row * XS + 8 * c) = xd[i]; continue; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xv = (float)(int)(int8_t)(xd[i] >> (8 * e));
-                    if (4 * c < NIM * 32) {
-                        if (XI8) sXb[(4 * c + e) * LD + row] = (int8_t)(xd[i] >> (8 * e));
-                        else sX[(4 * c + e) * LD + row] = xv;
-                    } else sXt[row * FT + (4 * c - NIM * 32) + e] = xv;
+                    for (int e = 0; e < 8; ++e) {
+                        if (XI8) sXb[(8 * c + e) * LD + row] = (int8_t)(xw[e >> 2] >> (8 * (e & 3)));
+                        else sX[(8 * c + e) * LD + row] = (float)(int)(int8_t)(xw[e >> 2] >> (8 * (e & 3)));
+                    }
+                } else {                                          // tail columns, row-major per tile row: two 16-byte writes
+                    float xv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = (float)(int)(int8_t)(xw[e >> 2] >> (8 * (e & 3)));
+                    float* xt = sXt + row * FT + (8 * c - NIM * 32);
+                    *reinterpret_cast<float4*>(xt) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                    *reinterpret_cast<float4*>(xt + 4) = make_float4(xv[4], xv[5], xv[6], xv[7]);
                 }
             }
         }
@@ -316,13 +341,15 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         // a SIMD (w and w + NT/2) run them at opposite ends of the phase, so one wave's VALU/LDS work sits
         // beside the other's MFMAs instead of both idling the matrix pipe together.
         auto small_grads = [&]() {
-            const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
+            const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;     // (Z2R: db2 is summed from phase C's A operands instead)
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
             const float* gy = sDY + 64 * h;
-            float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            float s2 = 0.f;
+            pk2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};                // v_pk_fma_f32: two of the four dW3 sums per instruction
 #pragma unroll 1
             for (int rc = 0; rc < 16; rc += 4) {                   // one 16-byte read per operand covers 4 rows
-                const float4 z4 = *reinterpret_cast<const float4*>(gz + rc);
+                float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (!Z2R) z4 = *reinterpret_cast<const float4*>(gz + rc);
                 const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
                 const float z[4] = {z4.x, z4.y, z4.z, z4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
                 float4 y[4];
@@ -331,11 +358,14 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    s2 += z[i]; d0 = fmaf(y[i].x, hv[i], d0); d1 = fmaf(y[i].y, hv[i], d1); d2 = fmaf(y[i].z, hv[i], d2); d3 = fmaf(y[i].w, hv[i], d3);
+                    if constexpr (!Z2R) s2 += z[i];
+                    const pk2 hh2 = {hv[i], hv[i]};
+                    d01 = pk_fma(pk2{y[i].x, y[i].y}, hh2, d01); d23 = pk_fma(pk2{y[i].z, y[i].w}, hh2, d23);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            db2 += s2; dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
+            if constexpr (!Z2R) db2 += s2;
+            dw3[0] += d01.x; dw3[1] += d01.y; dw3[2] += d23.x; dw3[3] += d23.y;
             if (tid < 4) {
                 float s = 0.f;
                 for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
@@ -355,20 +385,26 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
+            // B operand: Z2R: dZ2[row j][f = 8g + 4h + e], one 16-byte read per fragment group; else dZ2^T[f = 8g + 2e + h][row j]
+            const float* bz = Z2R ? sZ2 + j * RS + 4 * h : sZ2 + h * LD + j;
             const char* wn = w2t + (size_t)PF * 1024;                // scalar pointer to the next group set
             auto mfma_set = [&](const float4 (&rg)[PF]) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     float b[4];
+                    if constexpr (Z2R) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bz + 8 * u);
+                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                        for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
                 }
-                bz += 8 * PF * LD;
+                bz += Z2R ? 8 * PF : 8 * PF * LD;
             };
 #pragma unroll 1
             for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
@@ -394,7 +430,12 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         }
         if (!grads_first) small_grads();
         STAMP(2);
-        __syncthreads();
+        // No workgroup barrier between phases B and C/D: phase C reads this wave's own dZ2 rows and everybody's H1^T
+        // (complete since the barrier behind phase A), phase D this wave's own dZ1 rows (written by itself above) and
+        // X^T (phase A), and nothing in C/D writes LDS.  A wave that finishes its dH1 chain early goes straight on, so
+        // the two waves of a SIMD keep the skew grads_first gives them instead of being re-aligned here.
+        if constexpr (HID < PPO_BWD_BAR2_BELOW_HID) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's dZ1 writes have landed
         STAMP(3);
         // LDS-DMA of the next tile's layer-2 fragments into this wave's (now idle) sH2 slice.  Issued here, after
         // the barrier, by every wave: while a DMA is pending hipcc turns every counted vmcnt(N) into vmcnt(0), which
@@ -426,10 +467,11 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         s1 += z[ib + i];
+                        const pk2 zz = {z[ib + i], z[ib + i]};
 #pragma unroll
                         for (int c4 = 0; c4 < FT / 4; ++c4) {
-                            tl[4 * c4 + 0] = fmaf(z[ib + i], xv[i][c4].x, tl[4 * c4 + 0]); tl[4 * c4 + 1] = fmaf(z[ib + i], xv[i][c4].y, tl[4 * c4 + 1]);
-                            tl[4 * c4 + 2] = fmaf(z[ib + i], xv[i][c4].z, tl[4 * c4 + 2]); tl[4 * c4 + 3] = fmaf(z[ib + i], xv[i][c4].w, tl[4 * c4 + 3]);
+                            tl2[2 * c4 + 0] = pk_fma(zz, pk2{xv[i][c4].x, xv[i][c4].y}, tl2[2 * c4 + 0]);
+                            tl2[2 * c4 + 1] = pk_fma(zz, pk2{xv[i][c4].z, xv[i][c4].w}, tl2[2 * c4 + 1]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -440,11 +482,17 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         if (grads_first) tail_grads();
         {
             constexpr int KG = PPO_BWD_KG;                           // k-tiles whose B operands are in flight together
-            const float* pa = sZ2 + (32 * w + j) * LD + 16 * h;      // rows 16h .. 16h+15 of this lane's feature
+            // rows 16h .. 16h+15 of this lane's feature (Z2R: four 4-byte reads per step, and db2 is their sum)
+            const float* pa = Z2R ? sZ2 + (16 * h) * RS + 32 * w + j : sZ2 + (32 * w + j) * LD + 16 * h;
             const float* pb = sH1 + j * LD + 16 * h;
+            float s2 = 0.f;
 #pragma unroll 1
-            for (int q = 0; q < 4; ++q) {                            // 4 rows per LDS read
-                const float4 a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
+            for (int q = 0; q < 4; ++q) {                            // 4 rows per step
+                float4 a4;
+                if constexpr (Z2R) {
+                    a4 = make_float4(pa[(4 * q) * RS], pa[(4 * q + 1) * RS], pa[(4 * q + 2) * RS], pa[(4 * q + 3) * RS]);
+                    s2 += a4.x; s2 += a4.y; s2 += a4.z; s2 += a4.w;
+                } else a4 = *reinterpret_cast<const float4*>(pa + 4 * q);
 #pragma unroll
                 for (int kh = 0; kh < NT; kh += KG) {
                     float4 b4[KG];
@@ -459,6 +507,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
                     }
                 }
             }
+            if constexpr (Z2R) db2 += s2;
         }
         STAMP(7);
         // ================= phase D: dW1[k,i] += sum_rows dZ1[k,row] * X[i,row]     (wave w: k-tile w)
@@ -527,6 +576,9 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = accW1[it][r];
     if (FT > 0) {   // tail columns: combine the two row halves, then place them at their fragment-order positions of i-tile NIM
+        float tl[FT > 0 ? FT : 1];
+#pragma unroll
+        for (int c = 0; c < FT; ++c) tl[c] = (c & 1) ? tl2[c >> 1].y : tl2[c >> 1].x;
 #pragma unroll
         for (int c = 0; c < FT; ++c) tl[c] += __shfl_xor(tl[c], 32);
         if (h == 0) {
@@ -561,7 +613,8 @@ template <int F, int HID>
 static size_t bwd_lds_bytes() {
     const size_t xt = (size_t)(F / 32) * 32 * PPO_BWD_LD;      // X^T elements: floats, or bytes in the int8 forms
     const size_t xfl = BwdCfg<F, HID>::XN8 ? (size_t)32 * BwdCfg<F, HID>::XS / 4 : (BwdCfg<F, HID>::XI8 ? xt / 4 : xt);
-    return sizeof(float) * ((size_t)4 * HID * PPO_BWD_LD + xfl + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 + (size_t)HID * 4);
+    const size_t z2 = PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * PPO_BWD_LD;
+    return sizeof(float) * (z2 + (size_t)3 * HID * PPO_BWD_LD + xfl + (size_t)32 * ((F % 32) ? (F % 32) : 4) + 32 * 4 + (size_t)HID * 4);
 }
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {

@@ -36,8 +36,10 @@ template <int F, int HID>
 __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) {
     constexpr int NT = HID / 32, LD = SB_LD, S4 = HID / 8, FP = ((F + 31) / 32) * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sZ2 = smem;                          // [HID][LD] dZ2^T
-    float* sH2 = sZ2 + HID * LD;                // [HID][LD] H2^T
+    constexpr bool Z2R = PPO_BWD_Z2ROW_AT(HID);         // dZ2 row-major [32][RS] (16-byte B-operand reads, see k_policy_bwd)
+    constexpr int RS = HID + 4, Z2SZ = Z2R ? 32 * RS : HID * LD;
+    float* sZ2 = smem;                          // Z2R: dZ2 [32][RS]; else [HID][LD] dZ2^T
+    float* sH2 = sZ2 + Z2SZ;                    // [HID][LD] H2^T
     float* sZ1 = sH2 + HID * LD;                // [HID][LD] dZ1^T
     float* sDY = sZ1 + HID * LD;                // [32][4]
     float* sW3 = sDY + 32 * 4;                  // [HID][4]
@@ -93,9 +95,10 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
                 const int fo = e + 8 * q;
                 const float dh = dh2[4 * q + e];
                 z[e] = dh * (h2v[e] > 0.0f ? 1.0f : 0.01f);
-                z2b[fo * LD] = z[e];
+                if constexpr (!Z2R) z2b[fo * LD] = z[e];
                 h2b[fo * LD] = h2v[e];
             }
+            if constexpr (Z2R) *reinterpret_cast<float4*>(sZ2 + j * RS + fb + 8 * q) = make_float4(z[0], z[1], z[2], z[3]);
             zo[q * 64] = make_float4(z[0], z[1], z[2], z[3]);
         }
         __syncthreads();
@@ -111,13 +114,15 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
         if (tile + gridDim.x < a.B) fetch_tile(tile + gridDim.x);
         __builtin_amdgcn_sched_barrier(0);
         {
-            const float* gz = sZ2 + (32 * w + j) * LD + 16 * h;
+            const float* gz = Z2R ? sZ2 + (16 * h) * RS + 32 * w + j : sZ2 + (32 * w + j) * LD + 16 * h;
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
             const float* gy = sDY + 64 * h;
             float s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll 1
             for (int rc = 0; rc < 16; rc += 4) {
-                const float4 z4 = *reinterpret_cast<const float4*>(gz + rc);
+                float4 z4;
+                if constexpr (Z2R) z4 = make_float4(gz[rc * RS], gz[(rc + 1) * RS], gz[(rc + 2) * RS], gz[(rc + 3) * RS]);
+                else z4 = *reinterpret_cast<const float4*>(gz + rc);
                 const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
                 const float z[4] = {z4.x, z4.y, z4.z, z4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
@@ -137,19 +142,25 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float* bz = sZ2 + h * LD + j;                      // B operand: dZ2[f = 2s+h][row j]
+            // B operand: Z2R: dZ2[row j][f = 8g + 4h + e], one 16-byte read per fragment group; else dZ2^T[f = 8g + 2e + h][row j]
+            const float* bz = Z2R ? sZ2 + j * RS + 4 * h : sZ2 + h * LD + j;
             auto mfma_set = [&](const float4 (&rg)[PF]) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     float b[4];
+                    if constexpr (Z2R) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bz + 8 * u);
+                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                        for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
                 }
-                bz += 8 * PF * LD;
+                bz += Z2R ? 8 * PF : 8 * PF * LD;
             };
             const float4* wn = w2t + (size_t)PF * 64;
 #pragma unroll 1
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
 template <int F, int HID>
 static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     constexpr int NT = HID / 32, NI = (F + 31) / 32, WT = (1 + NI > 4) ? 1 + NI : 4;
-    const size_t lds_data = sizeof(float) * ((size_t)3 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
+    const size_t lds_data = sizeof(float) * ((PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * SB_LD) + (size_t)2 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
     const size_t lds_w = sizeof(float) * (size_t)4 * WT * 32 * SB_LD;
     static bool attr_set = false;
     if (!attr_set) {
