@@ -505,9 +505,9 @@ struct BwdBArgs {
 // working set, and one wave with > 256 accumulator registers spills.  So the pass is two kernels:
 //   k_policy_bwd_bf16  workgroup of 4 waves, one per SIMD with the whole register file; wave w owns feature tiles
 //                      w*FT .. w*FT+FT-1 of dW2 (256 accumulator registers = the AGPR half for HID = 256) and the
-//                      small grads.  It also emits, per tile, dZ1^T and X as ready-made MFMA operand fragments.
-//   k_policy_dw1_bf16  dW1 += dZ1^T X from those fragments: no LDS, no barriers, pure load + MFMA (the fragments
-//                      are 88 MB per 4096-state minibatch, written and re-read through the 256 MB Infinity Cache).
+//                      small grads.  It also emits, per tile, dZ1^T as ready-made MFMA operand fragments.
+//   k_policy_dw1_bf16  dW1 += dZ1^T X from the dZ1^T fragments (64 MB per 4096-state minibatch, written and re-read
+//                      through the 256 MB Infinity Cache) and the state rows themselves (9 MB).
 template <int F, int HID>
 struct BwdB {
     static constexpr int NT = HID / 32, NS = HID / 16, FP = ((F + 31) / 32) * 32, NI = FP / 32;
@@ -582,8 +582,10 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         for (int s = 0; s < NSH; ++s)
             sW[((w * FT + i) * NSH + s) * 64 + lane] = a.w2tb[((size_t)(w * FT + i) * NS + s) * 64 + lane];
 
+    constexpr bool FUSE1 = PPO_BF16_DW1_FUSED;
+    // the state rows are needed here only when dW1 is accumulated in this kernel (k_policy_dw1_bf16 stages its own)
     // zero the padded X image once (columns >= F are never written afterwards)
-    for (int i = tid; i < 32 * STX / 4; i += NTHR) reinterpret_cast<uint32_t*>(imgX)[i] = 0u;
+    if (FUSE1) for (int i = tid; i < 32 * STX / 4; i += NTHR) reinterpret_cast<uint32_t*>(imgX)[i] = 0u;
 
     f32x16 accW2[FT][NT];
 #pragma unroll
@@ -592,7 +594,6 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accW2[i][kt][r] = 0.0f;
-    constexpr bool FUSE1 = PPO_BF16_DW1_FUSED;
     f32x16 accW1[FUSE1 ? FT : 1][FUSE1 ? NI : 1];        // dW1[k-tiles of this wave][all input tiles] (columns >= F: zero padding)
     if (FUSE1) {
 #pragma unroll
@@ -653,11 +654,13 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16);
         }
         ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
-        const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
+        if constexpr (FUSE1) {
+            const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
-        for (int i = 0; i < XPD; ++i) {
-            const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
-            nx[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+            for (int i = 0; i < XPD; ++i) {
+                const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
+                nx[i] = d < (unsigned)XDW ? *reinterpret_cast<const uint32_t*>(xs + d * 4u) : 0u;
+            }
         }
     };
     // the same loads one at a time (piece k of 4 FT + 2), to be spread between the MFMAs of phase B: issued in one
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             else       nh2[i][k & 1] = ldg16_nt(a.act2b + base, lo16);
         } else if (k == 4 * FT) {
             ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
-        } else if (k == 4 * FT + 1) {
+        } else if (FUSE1 && k == 4 * FT + 1) {
             const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
             for (int i = 0; i < XPD; ++i) {
@@ -682,8 +685,8 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     auto tile_or_last = [&](int t) { return t < a.B ? t : a.B - 1; };
     int idx_next = 0;
     if ((int)blockIdx.x < a.B) {
-        prefetch((int)blockIdx.x, a.idx[(int)blockIdx.x >> a.tps_shift]);
-        idx_next = a.idx[tile_or_last((int)blockIdx.x + a.nwg) >> a.tps_shift];
+        prefetch((int)blockIdx.x, FUSE1 ? a.idx[(int)blockIdx.x >> a.tps_shift] : 0);
+        if (FUSE1) idx_next = a.idx[tile_or_last((int)blockIdx.x + a.nwg) >> a.tps_shift];
     }
     __syncthreads();
 
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         asm volatile("" : "+v"(lo16));
         const float4 dy = ndy;
 #pragma unroll
-        for (int i = 0; i < XPD; ++i) {
+        for (int i = 0; i < (FUSE1 ? XPD : 0); ++i) {
             if (xoff[i] >= 0) {
                 const uint32_t v = nx[i];
                 *reinterpret_cast<uint2*>(imgX + xoff[i]) =
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             static_assert(4 * FT + 2 <= NS, "one prefetch piece per k-step");
             constexpr int PF_T0 = 0;
             const int pf_tile = tile_or_last(tile + a.nwg), pf_sidx = __builtin_amdgcn_readfirstlane(idx_next);
-            idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
+            if (FUSE1) idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
             f32x16 acc[FT];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -912,8 +915,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) emit_z(i, s);
-#pragma unroll
-            for (int i = 0; i < FT; ++i) emit_x(i);
+            (void)emit_x;                                      // the dW1 kernel builds its X operands from the state rows itself
             }
         }
         __syncthreads();
@@ -967,44 +969,91 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     }
 }
 
-// dW1[k][i] += sum_rows dZ1[k][row] X[row][i] from the operand fragments of k_policy_bwd_bf16.  Same tile -> workgroup
-// assignment, so workgroup g fills the dW1 region of slab g.  Wave w owns k-tile w (NI accumulator tiles).
+// dW1[k][i] += sum_rows dZ1[k][row] X[row][i].  dZ1^T comes as ready-made operand fragments from k_policy_bwd_bf16
+// (16 KB per tile through the Infinity Cache); the X operands are built HERE from the tile's 2.3 KB of int8 state rows
+// (round 1 had the backward kernel emit them as fragments too: 6 KB written + 6 KB read per tile): the workgroup lays
+// the rows down as a row-major bf16 image in LDS, double-buffered so that one barrier per tile is enough, and every
+// wave reads its B operands back transposed (ds_read_b64_tr_b16).  Same tile -> workgroup assignment as the backward
+// kernel, so workgroup g fills the dW1 region of slab g.  Wave w owns k-tile w (NI accumulator tiles).
 template <int F, int HID>
 __global__ __launch_bounds__(HID * 2) void k_policy_dw1_bf16(BwdBArgs a) {
     using C = BwdB<F, HID>;
-    constexpr int NT = C::NT, NI = C::NI;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NT = C::NT, NI = C::NI, STX = C::STX, NTHR = HID * 2;
+    constexpr int XQW = 32 * F / 8;                              // 8-byte units of one tile's rows: thread u stages unit u
+    constexpr int XPD = (XQW + NTHR - 1) / NTHR;                 // staging passes (1 for HID = 256, F = 72)
+    static_assert(F % 8 == 0, "state rows are staged in 8-byte units");
+    __shared__ __attribute__((aligned(16))) char imgX[2][32 * STX];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * 32 * STX / 4; i += NTHR) reinterpret_cast<uint32_t*>(&imgX[0][0])[i] = 0u;   // pad columns stay zero
     f32x16 acc[NI];
 #pragma unroll
     for (int it = 0; it < NI; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[it][r] = 0.0f;
-    // next tile's fragments are fetched while the current tile's MFMAs run (two waves per SIMD, HBM/MALL-bound)
+    // transposed-read addressing of the X image (no swizzle; see k_policy_bwd_bf16)
+    const int tq = (lane & 15) >> 2, tcc = 4 * ((lane >> 4) & 1) + (lane & 3);
+    int trx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) trx[u] = (8 * h + 4 * u + tq) * STX + 8 * tcc;
+    int xw_off[XPD];                                             // image byte offset of this thread's 8 features
+#pragma unroll
+    for (int i = 0; i < XPD; ++i) { const int u = tid + i * NTHR; xw_off[i] = (u / (F / 8)) * STX + (u % (F / 8)) * 16; }
     const unsigned lo16 = (unsigned)lane * 16u;
-    uint4 z[2], x[NI][2];
-    auto fetch = [&](int t) {
+    // next tile's inputs are fetched while the current tile's MFMAs run (two waves per SIMD, HBM/MALL-bound); the
+    // transition id of the tile after that is fetched one tile earlier still (it is itself a global load)
+    uint4 z[2];
+    uint2 nx[XPD];
+#pragma unroll
+    for (int i = 0; i < XPD; ++i) nx[i] = make_uint2(0u, 0u);
+    auto tile_or_last = [&](int t) { return t < a.B ? t : a.B - 1; };
+    auto fetch = [&](int t, int sidx_v) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) z[s] = ldg16(a.z1f + (((size_t)t * NT + w) * 2 + s) * 64, lo16);
+        const int sidx = __builtin_amdgcn_readfirstlane(sidx_v);
+        const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
-        for (int it = 0; it < NI; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) x[it][s] = ldg16(a.xf + (((size_t)t * NI + it) * 2 + s) * 64, lo16);
+        for (int i = 0; i < XPD; ++i)
+            if (tid + i * NTHR < XQW) nx[i] = *reinterpret_cast<const uint2*>(xs + (unsigned)(tid + i * NTHR) * 8u);
     };
-    if ((int)blockIdx.x < a.B) fetch((int)blockIdx.x);
-    for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
-        uint4 cz[2], cx[NI][2];
+    int idx_next = 0;
+    if ((int)blockIdx.x < a.B) {
+        fetch((int)blockIdx.x, a.x_by_tile ? 0 : a.idx[(int)blockIdx.x >> a.tps_shift]);
+        if (!a.x_by_tile) idx_next = a.idx[tile_or_last((int)blockIdx.x + (int)gridDim.x) >> a.tps_shift];
+    }
+    __syncthreads();                                             // images zeroed
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.B; tile += gridDim.x, buf ^= 1) {
+        char* const img = &imgX[buf][0];
+#pragma unroll
+        for (int p = 0; p < XPD; ++p) {
+            if (tid + p * NTHR < XQW) {
+                float f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { f[i] = (float)(int)(int8_t)(nx[p].x >> (8 * i)); f[4 + i] = (float)(int)(int8_t)(nx[p].y >> (8 * i)); }
+                *reinterpret_cast<uint4*>(img + xw_off[p]) = make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+            }
+        }
+        uint4 cz[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) cz[s] = z[s];
+        // one barrier per tile: image `buf` is complete behind it, and nobody still reads the image the NEXT tile writes
+        // (its readers, one tile back, are all in front of this barrier)
+        __syncthreads();
+        {
+            const int nt = tile_or_last(tile + (int)gridDim.x);   // harmless re-load on the last tile
+            const int sidx = idx_next;
+            if (!a.x_by_tile) idx_next = a.idx[tile_or_last(tile + 2 * (int)gridDim.x) >> a.tps_shift];
+            fetch(nt, sidx);
+        }
 #pragma unroll
-        for (int it = 0; it < NI; ++it)
+        for (int s = 0; s < 2; ++s) {
+            uint4 xb[NI];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) cx[it][s] = x[it][s];
-        fetch((tile + (int)gridDim.x < a.B) ? tile + (int)gridDim.x : tile);      // harmless re-load on the last tile
+            for (int it = 0; it < NI; ++it) xb[it] = tr_frag(img + trx[0] + 16 * s * STX + 64 * it, img + trx[1] + 16 * s * STX + 64 * it);
 #pragma unroll
-        for (int it = 0; it < NI; ++it)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) acc[it] = mfma_bf16(cz[s], cx[it][s], acc[it]);
+            for (int it = 0; it < NI; ++it) acc[it] = mfma_bf16(cz[s], xb[it], acc[it]);
+        }
     }
     float* sW1 = a.slabs + (size_t)blockIdx.x * a.slab_stride + (size_t)HID * HID;
 #pragma unroll
