@@ -149,8 +149,9 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             int s, hh, jj;
             acc_kslot(k & 31, s, hh, jj);                // forward: out f, contraction k against packed H1 tiles
             P.w2b[((size_t)((f >> 5) * (HID / 16) + 2 * (k >> 5) + s) * 64 + (f & 31) + 32 * hh) * 8 + jj] = xb;
-            acc_kslot(f & 31, s, hh, jj);                // backward (W2^T): out k, contraction f against packed dZ2 tiles
-            P.w2tb[((size_t)((k >> 5) * (HID / 16) + 2 * (f >> 5) + s) * 64 + (k & 31) + 32 * hh) * 8 + jj] = xb;
+            // backward (W2^T): out k, contraction f in natural order (k-step f>>4, lane half (f>>3)&1, element f&7): the B
+            // operand is read straight from the row-major dZ2 image
+            P.w2tb[((size_t)((k >> 5) * (HID / 16) + (f >> 4)) * 64 + (k & 31) + 32 * ((f >> 3) & 1)) * 8 + (f & 7)] = xb;
         }
     } else if (i < L.offW3) {
         const int f = (int)(i - L.offb2), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);

@@ -518,8 +518,11 @@ struct BwdB {
     static_assert((ST / 4) % 64 == 16 || (ST / 4) % 64 == 48, "image stride");
     static_assert((STX / 4) % 64 == 16 || (STX / 4) % 64 == 48, "X image stride");
     static constexpr int IMG = 32 * ST;
-    static constexpr int oZ2 = 0, oH1 = IMG, oZ1 = 2 * IMG, oH2 = 3 * IMG, oZF = 4 * IMG, oX = oZF + NS * 1024,
-                         oDY = oX + 32 * STX, oW = oDY + 512, total = oW + NT * (NS / 2) * 1024;
+    // k-steps of W2^T resident in LDS for the whole launch (the rest streams from L2 once per tile into a register ring):
+    // three images (dZ1 reuses the H2 image, see phase B) + the X image leave room for 12 of the 16 at HID = 256
+    static constexpr int NSL = (HID >= 256) ? 12 : NS, NSR = NS - NSL;
+    static constexpr int oZ2 = 0, oH1 = IMG, oH2 = 2 * IMG, oX = 3 * IMG,
+                         oDY = oX + 32 * STX, oW = oDY + 512, total = oW + NT * NSL * 1024;
     static_assert(total <= 160 * 1024, "LDS budget");
 };
 
@@ -563,24 +566,23 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* const imgZ2 = smem_c + C::oZ2;
     char* const imgH1 = smem_c + C::oH1;
-    char* const imgZ1 = smem_c + C::oZ1;
     char* const imgH2 = smem_c + C::oH2;
-    uint4* const sZF = reinterpret_cast<uint4*>(smem_c + C::oZF);
+    char* const imgZ1 = imgH2;      // dZ1 overwrites H2: a wave's H2 columns are read by that wave only (dW3 sums, phase B) before it writes them
     char* const imgX = smem_c + C::oX;
     float* const sDY = reinterpret_cast<float*>(smem_c + C::oDY);
     uint4* const sW = reinterpret_cast<uint4*>(smem_c + C::oW);
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // the first half (k-steps 0 .. NS/2-1) of this wave's W2^T fragments stays in LDS for the whole launch (HID^2 bytes:
-    // all that is left of the 160 KiB next to the images); the second half streams from L2 once per tile and is
-    // issued at the top of the tile, so the dH1 chain of phase B never waits for a refill
-    constexpr int NSH = NS / 2;
+    // k-steps 0 .. NSL-1 of this wave's W2^T fragments stay in LDS for the whole launch (all that is left of the 160 KiB
+    // next to the images); the other NSR stream from L2 once per tile, issued through phase A, so the dH1 chain of
+    // phase B never waits for a refill
+    constexpr int NSL = C::NSL, NSR = C::NSR;
 #pragma unroll
     for (int i = 0; i < FT; ++i)
 #pragma unroll
-        for (int s = 0; s < NSH; ++s)
-            sW[((w * FT + i) * NSH + s) * 64 + lane] = a.w2tb[((size_t)(w * FT + i) * NS + s) * 64 + lane];
+        for (int s = 0; s < NSL; ++s)
+            sW[((w * FT + i) * NSL + s) * 64 + lane] = a.w2tb[((size_t)(w * FT + i) * NS + s) * 64 + lane];
 
     constexpr bool FUSE1 = PPO_BF16_DW1_FUSED;
     // the state rows are needed here only when dW1 is accumulated in this kernel (k_policy_dw1_bf16 stages its own)
@@ -609,11 +611,12 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
     for (int i = 0; i < FT; ++i) { db1[i] = db2[i] = 0.f; dw3[i][0] = dw3[i][1] = dw3[i][2] = dw3[i][3] = 0.f; }
 
     // A operands of dH2^T = W3^T dY^T for this wave's feature tiles: k = output index o (4 of the 16 k-slots used)
+    constexpr bool A3_RELOAD = FUSE1 && HID >= 256;      // register diet of the fused HID = 256 form: 2 x 4 registers back per tile from L2
     uint4 a3[FT];
 #pragma unroll
     for (int i = 0; i < FT; ++i) {
         a3[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (h == 0) { const uint2 t = a.w3tb[32 * (w * FT + i) + j]; a3[i].x = t.x; a3[i].y = t.y; }
+        if (!A3_RELOAD && h == 0) { const uint2 t = a.w3tb[32 * (w * FT + i) + j]; a3[i].x = t.x; a3[i].y = t.y; }
     }
 
     // image addressing.  Row-major [32 rows][cols] bf16, 8-byte chunk cc = col/4 stored at chunk cc ^ ((row>>1)&7):
@@ -714,15 +717,16 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         }
         // second half of this wave's W2^T fragments (L2-resident): issued at the top of the tile, right behind the wait
         // for the prefetched inputs, so they land under phase A (sched_barrier: hipcc otherwise sinks them to the barrier)
-        uint4 ring[NSH][FT];
+        uint4 ring[NSR > 0 ? NSR : 1][FT];
         const uint4* wt = a.w2tb + (size_t)(w * FT) * NS * 64;       // wave-uniform base of this wave's W2^T tiles
         // (k-step order = the order the chain consumes them in: vmcnt retires in order).  PPO_BF16_RING_SPREAD: not in
-        // one burst -- 16 KiB per wave through a 64 B/clk L1 stalls the issuing wave ~1000 cycles -- but a few at a
-        // time between the pieces of phase A's VALU/LDS work
-        auto ring_load = [&](int q) { ring[q / FT][q % FT] = ldg16(wt + (size_t)((q % FT) * NS + NSH + q / FT) * 64, lo16); };
-        constexpr bool SPREAD = PPO_BF16_RING_SPREAD && (NSH * FT == 4 + FT * 6);      // schedule written for HID = 256
+        // one burst -- 8 KiB per wave through a 64 B/clk L1 stalls the issuing wave ~500 cycles -- but a few at a
+        // time between the pieces of phase A's VALU/LDS work (2 here, then 3 per feature tile)
+        constexpr int NRL = NSR * FT;
+        auto ring_load = [&](int q) { if (q < NRL) ring[q / FT][q % FT] = ldg16(wt + (size_t)((q % FT) * NS + NSL + q / FT) * 64, lo16); };
+        constexpr bool SPREAD = PPO_BF16_RING_SPREAD && (NRL <= 2 + 3 * FT);
 #pragma unroll
-        for (int q = 0; q < (SPREAD ? 4 : NSH * FT); ++q) ring_load(q);
+        for (int q = 0; q < (SPREAD ? 2 : NRL); ++q) ring_load(q);
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
@@ -734,7 +738,10 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            acc = mfma_bf16(a3[i], bdy, acc);
+            uint4 a3i = make_uint4(0u, 0u, 0u, 0u);       // A operand of dH2^T = W3^T dY^T (k = output index: 4 of the 16 k-slots used)
+            if constexpr (A3_RELOAD) { if (h == 0) { const uint2 t = a.w3tb[32 * ft + j]; a3i.x = t.x; a3i.y = t.y; } }
+            else a3i = a3[i];
+            acc = mfma_bf16(a3i, bdy, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t d = dw(nh2[i][r >> 3], (r >> 1) & 3);
@@ -742,13 +749,11 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             }
             if constexpr (SPREAD) {
                 __builtin_amdgcn_sched_barrier(0);
-                ring_load(4 + 6 * i); ring_load(5 + 6 * i);
+                ring_load(2 + 3 * i);
                 __builtin_amdgcn_sched_barrier(0);
             }
             uint4 zf[2];
             pack_tile(acc, zf);
-            sZF[(2 * ft) * 64 + lane] = zf[0];
-            sZF[(2 * ft + 1) * 64 + lane] = zf[1];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
@@ -756,9 +761,11 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
                 *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[i][g >> 1], 2 * (g & 1)), dw(nh1[i][g >> 1], 2 * (g & 1) + 1));
                 if constexpr (SPREAD) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    ring_load(6 + 6 * i + g);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        ring_load(3 + 3 * i + g);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -779,18 +786,44 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+            // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
+            // MFMA tile that would be 7/8 zero padding): lane (f, h) holds rows 16s + 8h + e of column f.  Done HERE, in
+            // front of the chain: afterwards this wave's columns of the H2 image are free and take dZ1 (epilogue below)
+#pragma unroll
+            for (int i = 0; i < FT; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 hb = tr_frag(imgH2 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgH2 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t d = dw(hb, e >> 1);
+                        const float hv = (e & 1) ? bf16_hi(d) : bf16_lo(d);
+                        const float4 y = *reinterpret_cast<const float4*>(sDY + (16 * s + 8 * h + e) * 4);
+                        dw3[i][0] = fmaf(y.x, hv, dw3[i][0]); dw3[i][1] = fmaf(y.y, hv, dw3[i][1]);
+                        dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
             // The k-steps whose W2^T fragments were streamed into registers run first (their registers free up), then
             // the LDS-resident ones.  LDS operands are read DL steps ahead of their MFMAs (explicit queue; sched_barrier
             // pins the order): one step ahead covers 64 cycles of MFMA, a ds_read_b128 round trip is longer than that.
-            constexpr int DL = 3;
+            // B operand of k-step s: dZ2[row j][features 16s + 8h .. +7] straight from the row-major image -- chunks
+            // 4(s&1) + 2h and the next one of feature tile s>>1, each where the row's swizzle put it (two 8-byte reads;
+            // W2^T is packed in this natural contraction order)
+            constexpr int DL = (FUSE1 && HID >= 256) ? 2 : 3;
             uint4 bzq[DL], wlq[DL][FT];
-            auto kstep = [&](int t) { return t < NSH ? t + NSH : t - NSH; };
+            const char* const zrow = imgZ2 + wrow;
+            const int zc0 = 8 * ((2 * h) ^ wsw), zc1 = 8 * ((2 * h + 1) ^ wsw);        // byte offsets of the two chunks for even s; odd s: ^ 32
+            auto kstep = [&](int t) { return t < NSR ? t + NSL : t - NSR; };
             auto issue = [&](int t) {
                 const int s = kstep(t);
-                bzq[t % DL] = sZF[s * 64 + lane];
-                if (s < NSH) {
+                const char* zr = zrow + 64 * (s >> 1);
+                const uint2 lo = *reinterpret_cast<const uint2*>(zr + ((s & 1) ? (zc0 ^ 32) : zc0));
+                const uint2 hi = *reinterpret_cast<const uint2*>(zr + ((s & 1) ? (zc1 ^ 32) : zc1));
+                bzq[t % DL] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                if (s < NSL) {
 #pragma unroll
-                    for (int i = 0; i < FT; ++i) wlq[t % DL][i] = sW[((w * FT + i) * NSH + s) * 64 + lane];
+                    for (int i = 0; i < FT; ++i) wlq[t % DL][i] = sW[((w * FT + i) * NSL + s) * 64 + lane];
                 }
             };
 #pragma unroll
@@ -801,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 const uint4 bz = bzq[t % DL];
                 uint4 wv[FT];
 #pragma unroll
-                for (int i = 0; i < FT; ++i) wv[i] = (s < NSH) ? wlq[t % DL][i] : ring[s - NSH][i];
+                for (int i = 0; i < FT; ++i) wv[i] = (s < NSL) ? wlq[t % DL][i] : ring[s >= NSL ? s - NSL : 0][i];
                 if (t + DL < NS) issue(t + DL);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -874,22 +907,6 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                     for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
             }
             BSTAMP(5);
-            // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
-            // MFMA tile that would be 7/8 zero padding): lane (f, h) holds rows 16s + 8h + e of column f
-#pragma unroll
-            for (int i = 0; i < FT; ++i)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 hb = tr_frag(imgH2 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgH2 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t d = dw(hb, e >> 1);
-                        const float hv = (e & 1) ? bf16_hi(d) : bf16_lo(d);
-                        const float4 y = *reinterpret_cast<const float4*>(sDY + (16 * s + 8 * h + e) * 4);
-                        dw3[i][0] = fmaf(y.x, hv, dw3[i][0]); dw3[i][1] = fmaf(y.y, hv, dw3[i][1]);
-                        dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
-                    }
-                }
             BSTAMP(6);
             if constexpr (FUSE1) {
             // dW1[k][i] += sum_rows dZ1[k][row] X[row][i]: both operands come back transposed from their LDS images (the
