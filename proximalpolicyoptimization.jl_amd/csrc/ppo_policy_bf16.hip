@@ -48,6 +48,12 @@
 #define PPO_BF16_DW1_FUSED_MAX_HID 128
 #endif
 #define PPO_BF16_DW1_FUSED (HID <= PPO_BF16_DW1_FUSED_MAX_HID)
+#ifndef PPO_BF16_BWD_DL8
+#define PPO_BF16_BWD_DL8 2            // LDS operand queue depth of the dH1 chain in the 8-wave form (the partner wave covers the rest)
+#endif
+#ifndef PPO_BF16_BWD_WAVES
+#define PPO_BF16_BWD_WAVES 8          // waves per backward workgroup at HID = 256 (4 = one per SIMD, the round-1 form)
+#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -511,7 +517,10 @@ struct BwdBArgs {
 template <int F, int HID>
 struct BwdB {
     static constexpr int NT = HID / 32, NS = HID / 16, FP = ((F + 31) / 32) * 32, NI = FP / 32;
-    static constexpr int NW = 4, FT = NT / NW;            // waves per workgroup (one per SIMD), feature tiles per wave
+    // waves per workgroup and feature tiles per wave.  HID = 256: 8 waves, two per SIMD, one feature tile each (128 dW2
+    // accumulator registers + a working set that fits the other 128 now that only 4 k-steps of W2^T stream through
+    // registers): the partner wave covers the LDS / L2 round trips a single wave per SIMD sat through
+    static constexpr int NW = (HID >= 256) ? PPO_BF16_BWD_WAVES : 4, FT = NT / NW;
     static_assert(NT % NW == 0, "feature tiles per wave");
     static constexpr int ST = 2 * HID + 64;               // image row stride (bytes): 16 dwords mod 64 -> the 4 rows of a
     static constexpr int STX = 2 * FP;                    //   transposed-read block sit on different bank quarters
@@ -522,7 +531,7 @@ struct BwdB {
     // three images (dZ1 reuses the H2 image, see phase B) + the X image leave room for 12 of the 16 at HID = 256
     static constexpr int NSL = (HID >= 256) ? 12 : NS, NSR = NS - NSL;
     static constexpr int oZ2 = 0, oH1 = IMG, oH2 = 2 * IMG, oX = 3 * IMG,
-                         oDY = oX + 32 * STX, oW = oDY + 512, total = oW + NT * NSL * 1024;
+                         oDY = oX + 32 * STX, oDB3 = oDY + 512, oW = oDB3 + 512, total = oW + NT * NSL * 1024;
     static_assert(total <= 160 * 1024, "LDS budget");
 };
 
@@ -542,6 +551,12 @@ __device__ __forceinline__ uint4 ldg16_nt(const void* sbase, unsigned voff) {
     return ldg16(sbase, voff);
 #endif
 }
+__device__ __forceinline__ float4 ldg16f(const void* sbase, unsigned voff) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbase) + voff);
+}
+__device__ __forceinline__ uint2 ldg8(const void* sbase, unsigned voff) {
+    return *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(sbase) + voff);
+}
 __device__ __forceinline__ void stg16(void* sbase, unsigned voff, const uint4& v) {
     *reinterpret_cast<uint4*>(reinterpret_cast<char*>(sbase) + voff) = v;
 }
@@ -559,9 +574,9 @@ __device__ __forceinline__ float sum_frag(const uint4& v) {
 }
 
 template <int F, int HID>
-__global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
+__global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(BwdBArgs a) {
     using C = BwdB<F, HID>;
-    constexpr int NT = C::NT, NS = C::NS, NI = C::NI, FT = C::FT, ST = C::ST, STX = C::STX, NTHR = 256;
+    constexpr int NT = C::NT, NS = C::NS, NI = C::NI, FT = C::FT, ST = C::ST, STX = C::STX, NTHR = C::NW * 64;
     constexpr int XDW = 32 * F / 4, XPD = (XDW + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* const imgZ2 = smem_c + C::oZ2;
@@ -606,12 +621,16 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 for (int r = 0; r < 16; ++r) accW1[FUSE1 ? i : 0][FUSE1 ? it : 0][r] = 0.0f;
     }
     float db1[FT], db2[FT], dw3[FT][4];
-    float4 db3 = make_float4(0.f, 0.f, 0.f, 0.f);        // per-row partial sums of dY (combined over the 32 rows at the end)
+    // per-row partial sums of dY (combined over the 32 rows at the end): wave 0 keeps them in LDS, not in four registers
+    // that every wave would carry through the whole tile loop
+    float4* const sDB3 = reinterpret_cast<float4*>(smem_c + C::oDB3);
+    if (w == 0 && h == 0) sDB3[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < FT; ++i) { db1[i] = db2[i] = 0.f; dw3[i][0] = dw3[i][1] = dw3[i][2] = dw3[i][3] = 0.f; }
 
     // A operands of dH2^T = W3^T dY^T for this wave's feature tiles: k = output index o (4 of the 16 k-slots used)
-    constexpr bool A3_RELOAD = FUSE1 && HID >= 256;      // register diet of the fused HID = 256 form: 2 x 4 registers back per tile from L2
+    constexpr bool DIET = C::NW > 4;                     // two waves per SIMD: 128 registers beside the accumulators
+    constexpr bool A3_RELOAD = DIET;                     // W3^T operand (4 registers per feature tile) back per tile from L2
     uint4 a3[FT];
 #pragma unroll
     for (int i = 0; i < FT; ++i) {
@@ -656,7 +675,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             nh2[i][0] = ldg16_nt(a.act2b + base, lo16); nh2[i][1] = ldg16_nt(a.act2b + base + 64, lo16);
             nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16);
         }
-        ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+        ndy = ldg16f(a.dY + (size_t)t * 32, lo16 & 0x1F0u);                     // row j: (lane & 31) * 16 bytes
         if constexpr (FUSE1) {
             const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
@@ -675,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             if (k & 2) nh1[i][k & 1] = ldg16_nt(a.act1b + base, lo16);
             else       nh2[i][k & 1] = ldg16_nt(a.act2b + base, lo16);
         } else if (k == 4 * FT) {
-            ndy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+            ndy = ldg16f(a.dY + (size_t)t * 32, lo16 & 0x1F0u);                     // row j: (lane & 31) * 16 bytes
         } else if (FUSE1 && k == 4 * FT + 1) {
             const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
 #pragma unroll
@@ -730,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
-        db3.x += dy.x; db3.y += dy.y; db3.z += dy.z; db3.w += dy.w;
+        if (w == 0 && h == 0) { float4 t = sDB3[j]; t.x += dy.x; t.y += dy.y; t.z += dy.z; t.w += dy.w; sDB3[j] = t; }
         const uint4 bdy = (h == 0) ? make_uint4(dy01, dy23, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int i = 0; i < FT; ++i) {
@@ -739,7 +758,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             uint4 a3i = make_uint4(0u, 0u, 0u, 0u);       // A operand of dH2^T = W3^T dY^T (k = output index: 4 of the 16 k-slots used)
-            if constexpr (A3_RELOAD) { if (h == 0) { const uint2 t = a.w3tb[32 * ft + j]; a3i.x = t.x; a3i.y = t.y; } }
+            if constexpr (A3_RELOAD) { if (h == 0) { const uint2 t = ldg8(a.w3tb + 32 * ft, (lo16 & 0x1F0u) >> 1); a3i.x = t.x; a3i.y = t.y; } }
             else a3i = a3[i];
             acc = mfma_bf16(a3i, bdy, acc);
 #pragma unroll
@@ -810,7 +829,13 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
             // B operand of k-step s: dZ2[row j][features 16s + 8h .. +7] straight from the row-major image -- chunks
             // 4(s&1) + 2h and the next one of feature tile s>>1, each where the row's swizzle put it (two 8-byte reads;
             // W2^T is packed in this natural contraction order)
-            constexpr int DL = (FUSE1 && HID >= 256) ? 2 : 3;
+            constexpr int DL = DIET ? PPO_BF16_BWD_DL8 : 3;
+            // this wave's resident W2^T fragments behind ONE opaque per-lane base: the k-step offsets then fit the ds_read
+            // immediate (with the array base folded in they pass 64 KiB, and hipcc hoists one address register per k-step
+            // out of the tile loop -- which spill, and every scratch reload waits vmcnt(0), i.e. for the whole prefetch)
+            unsigned swl_a = (unsigned)(size_t)(PPO_LDS void*)(sW + (size_t)(w * FT) * NSL * 64 + lane);
+            asm volatile("" : "+v"(swl_a));
+            const PPO_LDS u32x4* const swl = (const PPO_LDS u32x4*)(size_t)swl_a;
             uint4 bzq[DL], wlq[DL][FT];
             const char* const zrow = imgZ2 + wrow;
             const int zc0 = 8 * ((2 * h) ^ wsw), zc1 = 8 * ((2 * h + 1) ^ wsw);        // byte offsets of the two chunks for even s; odd s: ^ 32
@@ -823,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
                 bzq[t % DL] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                 if (s < NSL) {
 #pragma unroll
-                    for (int i = 0; i < FT; ++i) wlq[t % DL][i] = sW[((w * FT + i) * NSL + s) * 64 + lane];
+                    for (int i = 0; i < FT; ++i) { const u32x4 t4 = swl[(i * NSL + s) * 64]; wlq[t % DL][i] = make_uint4(t4.x, t4.y, t4.z, t4.w); }
                 }
             };
 #pragma unroll
@@ -939,7 +964,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         BSTAMP(7);
     }
 #ifdef PPO_BF16_STAMP
-    if (a.stamps && lane == 0)
+    if (a.stamps && lane == 0 && w < 4)
         for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 4 + w) * 8 + i] = st_sum[i];
 #endif
 
@@ -976,6 +1001,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_bwd_bf16(BwdBArgs a) {
         }
     }
     if (w == 0) {
+        const float4 db3 = sDB3[j];                           // (lanes 32..63 read the same rows: the butterfly below stays inside a half)
         float t4[4] = {db3.x, db3.y, db3.z, db3.w};
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
@@ -1124,7 +1150,7 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
         }                                                                                                         \
         {                                                                                                         \
             ProfScope ps("k_policy_bwd");                                                                         \
-            hipLaunchKernelGGL((k_policy_bwd_bf16<FF, HH>), dim3(nwg), dim3(256), lds, ppo_stream(), a);       \
+            hipLaunchKernelGGL((k_policy_bwd_bf16<FF, HH>), dim3(nwg), dim3(BwdB<FF, HH>::NW * 64), lds, ppo_stream(), a); \
         }                                                                                                         \
         if (HH > PPO_BF16_DW1_FUSED_MAX_HID) {                                                                    \
             ProfScope ps("k_policy_dw1");                                                                         \
