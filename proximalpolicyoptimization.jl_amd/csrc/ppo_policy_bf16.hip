@@ -48,6 +48,13 @@
 #define PPO_BF16_DW1_FUSED_MAX_HID 128
 #endif
 #define PPO_BF16_DW1_FUSED (HID <= PPO_BF16_DW1_FUSED_MAX_HID)
+// The backward kernel recomputes H1 = lrelu(W1 X + b1) of its feature tiles (KS1 MFMAs per tile from the 2.3 KB of
+// state rows + L2-resident W1 fragments) instead of reading what the train forward saved: 16 KB per tile less written
+// by the forward and 16 KB less read here -- a third of the training step's HBM bytes.  Same operand order as the
+// forward, so the recomputed tile is bit-identical to the one that was saved.
+#ifndef PPO_BF16_H1_RECOMPUTE
+#define PPO_BF16_H1_RECOMPUTE 1
+#endif
 #ifndef PPO_BF16_BWD_DL8
 #define PPO_BF16_BWD_DL8 2            // LDS operand queue depth of the dH1 chain in the 8-wave form (the partner wave covers the rest)
 #endif
@@ -93,6 +100,13 @@ __device__ __forceinline__ void act_store_nt_u4(uint4* p, const uint4& v) {
 __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // ================================================================ forward
+// waves per forward workgroup (one workgroup per CU: W2 takes 128 KiB of its LDS): 8 = two per SIMD with 256 registers,
+// 12 = three per SIMD with 168
+#ifndef PPO_BF16_FWD_WAVES
+#define PPO_BF16_FWD_WAVES 8
+#endif
+#define FWB_W PPO_BF16_FWD_WAVES
+#define FWB_T (PPO_BF16_FWD_WAVES * 64)
 template <int F, int HID>
 struct FwdB {
     static constexpr int NT = HID / 32, NS = HID / 16, KS1 = (F + 15) / 16;
@@ -102,7 +116,7 @@ struct FwdB {
 };
 
 template <int F, int HID, int MODE, int TPS>
-__global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
+__global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs a) {
     using C = FwdB<F, HID>;
     constexpr int NT = C::NT, NS = C::NS, KS1 = C::KS1;
     constexpr bool TRAIN = (MODE == 2 || MODE == 4);    // train forward: saves activations, loss tail
@@ -124,21 +138,20 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #define FBSTAMP(i) do {} while (0)
 #endif
     {   // unrolled: all the loads are in flight before the first LDS write waits for one (the rolled loop was 4 us slower)
-        constexpr int NCH = C::W2_U4 / 512;
-        static_assert(C::W2_U4 % 512 == 0, "W2 staging chunks");
+        constexpr int NCH = (C::W2_U4 + FWB_T - 1) / FWB_T;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) sW2[k * 512 + tid] = a.w2b[k * 512 + tid];
+        for (int k = 0; k < NCH; ++k) if (C::W2_U4 % FWB_T == 0 || k * FWB_T + tid < C::W2_U4) sW2[k * FWB_T + tid] = a.w2b[k * FWB_T + tid];
     }
-    for (int i = tid; i < NS * 8; i += 512) sW3[i] = a.w3c[i];
+    for (int i = tid; i < NS * 8; i += FWB_T) sW3[i] = a.w3c[i];
     if (tid == 0) sW3[NS * 8] = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < NT * 8; i += 512) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    for (int i = tid; i < NT * 8; i += FWB_T) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
     __syncthreads();
     // layer-3 A operand: rows 0..3 of the 32-row operand tile are W3, the rest zero (lanes j >= 4 read the zero block)
     const int w3_lane = (j < 4) ? (h * 4 + j) : -1;
 
     // ---- MODE 3: persistent rollout (see k_policy_fwd): every wave walks its envs through all T steps; W2 is staged in
     // LDS once per ROLLOUT instead of once per step.  Env state lives in the wave's LDS slots.
-    const int64_t wave0 = (int64_t)blockIdx.x * 8 + w, nwaves = (int64_t)gridDim.x * 8;
+    const int64_t wave0 = (int64_t)blockIdx.x * FWB_W + w, nwaves = (int64_t)gridDim.x * FWB_W;
     const int slot_bytes = 2 * a.envV + 32;
     char* const my_slots = env_lds + (size_t)w * a.env_slots * slot_bytes;
     EnvConst ec = {};
@@ -169,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #if PPO_BF16_TMPL_LDS
             // the 32 template rows (36 ids each) sit behind the env slots in LDS: nine registers less to carry through
             // the tile loop (they spilled, and every scratch reload waits on vmcnt behind the rollout-column stores)
-            uint32_t* tl = reinterpret_cast<uint32_t*>(env_lds + (size_t)8 * a.env_slots * slot_bytes);
-            for (int i = tid; i < 32 * PPO_TPL / 4; i += 512) tl[i] = reinterpret_cast<const uint32_t*>(a.env_tmpl)[i];
+            uint32_t* tl = reinterpret_cast<uint32_t*>(env_lds + (size_t)FWB_W * a.env_slots * slot_bytes);
+            for (int i = tid; i < 32 * PPO_TPL / 4; i += FWB_T) tl[i] = reinterpret_cast<const uint32_t*>(a.env_tmpl)[i];
             __syncthreads();
 #else
             const uint32_t* tp = reinterpret_cast<const uint32_t*>(a.env_tmpl + j * PPO_TPL);
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) tid9[k] = tmpl_regs[k];
 #if PPO_BF16_TMPL_LDS
-                    const uint32_t* tl = reinterpret_cast<const uint32_t*>(env_lds + (size_t)8 * a.env_slots * slot_bytes) + j * (PPO_TPL / 4);
+                    const uint32_t* tl = reinterpret_cast<const uint32_t*>(env_lds + (size_t)FWB_W * a.env_slots * slot_bytes) + j * (PPO_TPL / 4);
 #pragma unroll
                     for (int k = 0; k < 9; ++k) tid9[k] = tl[k];
 #endif
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
                     pack_tile(acc, h1p[o]);
-                    if (TRAIN && !PPO_BF16_STORE_LATE) {
+                    if (TRAIN && !PPO_BF16_STORE_LATE && a.act1b) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
                     }
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void k_policy_fwd_bf16(FwdArgs a) {
                 // saved layer-1 activations leave AFTER the last W1 fragment has been waited for: loads and stores share
                 // the in-order vmcnt queue, so a store between two ring loads puts its HBM round trip on the MFMA chain
                 // (layer 2 takes its operands from LDS and never waits on vmcnt)
-                if (TRAIN && PPO_BF16_STORE_LATE) {
+                if (TRAIN && PPO_BF16_STORE_LATE && a.act1b) {        // (null: the backward kernel recomputes H1)
 #pragma unroll
                     for (int o = 0; o < NT; ++o) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
@@ -426,19 +439,19 @@ static void set_fwd_stamps(FwdArgs&) {}
 template <int MODE>
 static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B, int tps) {
     set_fwd_stamps(const_cast<FwdArgs&>(args));
-    const int64_t need = (B + 7) / 8;
+    const int64_t need = (B + FWB_W - 1) / FWB_W;
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
 #define LAUNCHB(FF, HH, TT)                                                                                          \
     do {                                                                                                             \
         /* MODE 4: one env-snapshot slot per wave + the template rows behind them */                               \
-        const size_t lds = FwdB<FF, HH>::lds_bytes + (MODE == 4 ? (size_t)8 * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
+        const size_t lds = FwdB<FF, HH>::lds_bytes + (MODE == 4 ? (size_t)FWB_W * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
         static size_t attr_lds = 0;                                                                                  \
         if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<FF, HH, MODE, TT>,                            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
             attr_lds = lds;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_policy_fwd_bf16<FF, HH, MODE, TT>), dim3(grid), dim3(512), lds, ppo_stream(), args);   \
+        hipLaunchKernelGGL((k_policy_fwd_bf16<FF, HH, MODE, TT>), dim3(grid), dim3(FWB_T), lds, ppo_stream(), args); \
     } while (0)
     if (p->F == 72 && p->HID == 256 && tps == 1) LAUNCHB(72, 256, 1);
     else if (p->F == 72 && p->HID == 256 && tps == 4) LAUNCHB(72, 256, 4);
@@ -452,13 +465,13 @@ static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B
 
 // persistent rollout in bf16 mode: `a` comes filled from launch_policy_rollout_persistent (ppo_policy_fwd.hip)
 int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V) {
-    const int64_t need = (N + 7) / 8;
+    const int64_t need = (N + FWB_W - 1) / FWB_W;
     const unsigned grid = (unsigned)(need < 256 ? need : 256);
-    const int slots = (int)((N + (int64_t)grid * 8 - 1) / ((int64_t)grid * 8));
+    const int slots = (int)((N + (int64_t)grid * FWB_W - 1) / ((int64_t)grid * FWB_W));
     a.env_slots = slots;
     set_fwd_stamps(a);
     a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
-    const size_t env_bytes = (size_t)8 * slots * (2 * V + 32) + 32 * PPO_TPL;      // env slots + the template rows
+    const size_t env_bytes = (size_t)FWB_W * slots * (2 * V + 32) + 32 * PPO_TPL;  // env slots + the template rows
 #define LAUNCHP(HH, TT)                                                                                              \
     do {                                                                                                             \
         const size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                      \
@@ -469,7 +482,7 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
             attr_lds = lds;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((k_policy_fwd_bf16<72, HH, 3, TT>), dim3(grid), dim3(512), lds, ppo_stream(), a);         \
+        hipLaunchKernelGGL((k_policy_fwd_bf16<72, HH, 3, TT>), dim3(grid), dim3(FWB_T), lds, ppo_stream(), a);       \
     } while (0)
     if (p->HID == 256 && tps == 1) LAUNCHP(256, 1);
     else if (p->HID == 128 && tps == 1) LAUNCHP(128, 1);
@@ -481,7 +494,7 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
 
 int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& a, int mode, int64_t B, int tps) {
     a.w1b = (const uint4*)p->w1b.p; a.w2b = (const uint4*)p->w2b.p; a.w3c = (const uint4*)p->w3c.p;
-    a.act1b = (uint4*)p->act1.p; a.act2b = (uint4*)p->act2.p;
+    a.act1b = PPO_BF16_H1_RECOMPUTE ? nullptr : (uint4*)p->act1.p; a.act2b = (uint4*)p->act2.p;
     if (mode == 0) return dispatch_fwd_bf16<0>(p, a, B, tps);
     if (mode == 1) return dispatch_fwd_bf16<1>(p, a, B, tps);
     if (mode == 4) return dispatch_fwd_bf16<4>(p, a, B, tps);
@@ -496,6 +509,7 @@ struct BwdBArgs {
     int nwg;                                                // == gridDim.x (as an argument: no dispatch-packet reload in the loop)
     const uint4* act1b; const uint4* act2b; const float4* dY;
     const uint4* w2tb; const uint2* w3tb;
+    const uint4* w1b; const float4* b1p;                    // layer-1 fragments / bias pack (H1 recomputed here)
     uint4* z1f; uint4* xf;                                  // operand fragments handed to k_policy_dw1_bf16
     float* slabs; size_t slab_stride;
     unsigned long long* stamps;                             // diagnostic build only (-DPPO_BF16_STAMP)
@@ -531,7 +545,14 @@ struct BwdB {
     // three images (dZ1 reuses the H2 image, see phase B) + the X image leave room for 12 of the 16 at HID = 256
     static constexpr int NSL = (HID >= 256) ? 12 : NS, NSR = NS - NSL;
     static constexpr int oZ2 = 0, oH1 = IMG, oH2 = 2 * IMG, oX = 3 * IMG,
-                         oDY = oX + 32 * STX, oDB3 = oDY + 512, oW = oDB3 + 512, total = oW + NT * NSL * 1024;
+                         oDY = oX + 32 * STX, oDB3 = oDY + 512, oB1 = oDB3 + 512, oW = oB1 + NT * 128,
+                         wEnd = oW + NT * NSL * 1024;
+    static constexpr int KS1 = (F + 15) / 16;             // layer-1 k-steps
+    static constexpr bool FUSE = (HID <= PPO_BF16_DW1_FUSED_MAX_HID);
+    // layer-1 B operands (X as bf16 fragments, KS1 KiB) of the tile about to be processed: where the X image would be
+    // when dW1 is not accumulated here, behind the weights otherwise
+    static constexpr int oXF = FUSE ? wEnd : oX, total = FUSE ? wEnd + (KS1 + 1) * 1024 : wEnd;     // + one spare slot
+    static_assert((KS1 + 1) * 1024 <= 32 * STX, "X fragments fit the X image's place");
     static_assert(total <= 160 * 1024, "LDS budget");
 };
 
@@ -586,8 +607,13 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
     char* const imgX = smem_c + C::oX;
     float* const sDY = reinterpret_cast<float*>(smem_c + C::oDY);
     uint4* const sW = reinterpret_cast<uint4*>(smem_c + C::oW);
+    float4* const sB1 = reinterpret_cast<float4*>(smem_c + C::oB1);
+    u32x4* const sXF = reinterpret_cast<u32x4*>(smem_c + C::oXF);
+    constexpr bool RC1 = PPO_BF16_H1_RECOMPUTE;
+    constexpr int KS1 = C::KS1;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (RC1) for (int i = tid; i < NT * 8; i += C::NW * 64) sB1[i] = a.b1p[i];
 
     // k-steps 0 .. NSL-1 of this wave's W2^T fragments stay in LDS for the whole launch (all that is left of the 160 KiB
     // next to the images); the other NSR stream from L2 once per tile, issued through phase A, so the dH1 chain of
@@ -641,8 +667,10 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
     // image addressing.  Row-major [32 rows][cols] bf16, 8-byte chunk cc = col/4 stored at chunk cc ^ ((row>>1)&7):
     // the 16 lanes of a ds_write_b64 group (16 consecutive rows, same chunk) then hit 16 different bank pairs.
     // write side: lane (row j, half h) owns chunks 8*tile + 2g + h, g = 0..3
-    const int wsw = (j >> 1) & 7;
-    const int wrow = j * ST;
+    // (re-derived from an opaque copy of j at the top of every phase that uses them: hoisted out of the tile loop the
+    // swizzled addresses are a dozen registers that spill, and a scratch reload waits vmcnt(0))
+    int jt = j;
+#define BF16_SWZ() asm volatile("" : "+v"(jt)); const int wsw = (jt >> 1) & 7, wrow = jt * ST
     // transposed-read side (operand lane l: column l&31, rows 8h + 4u + q of k-step s; q = (l&15)>>2 supplies the row,
     // p = l&3 the 4-column chunk, (l>>4)&1 the 16-column block of the 32-column tile)
     const int tq = (lane & 15) >> 2, tcc = 4 * ((lane >> 4) & 1) + (lane & 3);
@@ -654,9 +682,13 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         trx[u] = r * STX + 8 * tcc;                        // X image: no swizzle
     }
 
-    // next tile's inputs, fetched one tile ahead (one wave per SIMD: nobody else hides the HBM latency)
-    uint4 nh2[FT][2], nh1[FT][2];
+    // next tile's inputs, fetched one tile ahead
+    uint4 nh2[FT][2], nh1[RC1 ? 1 : FT][2];
     float4 ndy;
+    constexpr int KPW = (KS1 + C::NW - 1) / C::NW;          // layer-1 k-steps a wave converts: w, w + NW, ...
+    uint2 nxr[KPW];                                         // RC1: this lane's 8 state bytes of those k-steps
+#pragma unroll
+    for (int q = 0; q < KPW; ++q) nxr[q] = make_uint2(0u, 0u);
     uint32_t nx[XPD];
     int xoff[XPD];                                          // X-image byte offset of state dword tid + i*256 (tile-independent)
 #pragma unroll
@@ -665,6 +697,37 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         xoff[i] = (d < XDW) ? (d / (F / 4)) * STX + (d % (F / 4)) * 8 : -1;
     }
     unsigned lo16 = (unsigned)lane * 16u;
+    auto rows_of = [&](int t, int sidx) {                   // first byte of tile t's 32 state rows (wave-uniform)
+        return reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
+    };
+    // layer-1 B operand of k-step s = w: lane (row j, half h) holds features 16w + 8h .. +7 of its row -- exactly 8
+    // consecutive state bytes (none for the half that lies beyond F)
+    auto load_xraw = [&](int t, int sidx) {
+        // branch-free (a wave-uniform branch inside the unrolled dH1 chain splits its scheduling region): a wave without a
+        // k-step loads the last one again and never stores it; the half beyond F loads its row's first bytes and is zeroed
+        // at the store
+#pragma unroll
+        for (int q = 0; q < KPW; ++q) {
+            const int s0 = w + C::NW * q, ws = s0 < KS1 ? s0 : KS1 - 1;
+            const bool in = 16 * ws + 8 * h + 8 <= F;
+            const unsigned off = (lo16 & 0x1F0u) / 16u * (unsigned)F + (in ? 16u * (unsigned)ws + ((lo16 >> 9) & 1u) * 8u : 0u);
+            nxr[q] = ldg8(rows_of(t, sidx), off);
+        }
+    };
+    auto store_xfrag = [&]() {                              // nxr -> bf16 fragments -> sXF[k-step]
+#pragma unroll
+        for (int q = 0; q < KPW; ++q) {
+            // branch-free as well: a wave without a k-step writes the spare slot KS1 (nobody reads it)
+            const int s0 = w + C::NW * q, sl = s0 < KS1 ? s0 : KS1;
+            uint2 d = nxr[q];
+            if (16 * sl + 8 * h + 8 > F) d = make_uint2(0u, 0u);
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[i] = (float)(int)(int8_t)(d.x >> (8 * i)); f[4 + i] = (float)(int)(int8_t)(d.y >> (8 * i)); }
+            const u32x4 v = {pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7])};
+            sXF[sl * 64 + lane] = v;
+        }
+    };
     // sidx: transition id of tile t's state.  It is itself a global load, so it is fetched one tile earlier still
     // (idx_next below): a prefetch that first had to wait for its own index stalled phase B for an HBM round trip.
     auto prefetch = [&](int t, int sidx_v) {
@@ -673,11 +736,11 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         for (int i = 0; i < FT; ++i) {
             const size_t base = ((size_t)t * NT + (w * FT + i)) * 128;          // wave-uniform
             nh2[i][0] = ldg16_nt(a.act2b + base, lo16); nh2[i][1] = ldg16_nt(a.act2b + base + 64, lo16);
-            nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16);
+            if constexpr (!RC1) { nh1[i][0] = ldg16_nt(a.act1b + base, lo16); nh1[i][1] = ldg16_nt(a.act1b + base + 64, lo16); }
         }
         ndy = ldg16f(a.dY + (size_t)t * 32, lo16 & 0x1F0u);                     // row j: (lane & 31) * 16 bytes
         if constexpr (FUSE1) {
-            const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
+            const char* xs = rows_of(t, sidx);
 #pragma unroll
             for (int i = 0; i < XPD; ++i) {
                 const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
@@ -685,18 +748,23 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             }
         }
     };
-    // the same loads one at a time (piece k of 4 FT + 2), to be spread between the MFMAs of phase B: issued in one
-    // burst they stall the wave for ~1200 cycles (the CU's miss queue back-pressures the issue), and nothing overlaps
-    auto prefetch_piece = [&](int k, int t, int sidx) {
-        if (k < 4 * FT) {
-            const int i = k >> 2;
+    // the same loads one at a time, to be spread between the MFMAs of phase B: issued in one burst they stall the wave
+    // for ~1200 cycles (the CU's miss queue back-pressures the issue), and nothing overlaps.  Piece 0 is the state
+    // bytes (the first thing consumed: converted at the end of this tile's phase C), then H2 (and H1), dY, X image
+    constexpr int NPA = RC1 ? 2 * FT : 4 * FT;              // activation pieces
+    constexpr int NPIECE = 1 + NPA + 2;
+    auto prefetch_piece = [&](int k0, int t, int sidx) {
+        if (k0 == 0) { if constexpr (RC1) load_xraw(t, sidx); return; }
+        const int k = k0 - 1;
+        if (k < NPA) {
+            const int i = RC1 ? (k >> 1) : (k >> 2);
             const size_t base = ((size_t)t * NT + (w * FT + i)) * 128 + ((k & 1) ? 64 : 0);
-            if (k & 2) nh1[i][k & 1] = ldg16_nt(a.act1b + base, lo16);
-            else       nh2[i][k & 1] = ldg16_nt(a.act2b + base, lo16);
-        } else if (k == 4 * FT) {
+            if (!RC1 && (k & 2)) nh1[RC1 ? 0 : i][k & 1] = ldg16_nt(a.act1b + base, lo16);
+            else                 nh2[i][k & 1] = ldg16_nt(a.act2b + base, lo16);
+        } else if (k == NPA) {
             ndy = ldg16f(a.dY + (size_t)t * 32, lo16 & 0x1F0u);                     // row j: (lane & 31) * 16 bytes
-        } else if (FUSE1 && k == 4 * FT + 1) {
-            const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : (((size_t)sidx << a.tps_shift) + (size_t)(t & ((1 << a.tps_shift) - 1)))) * 32 * F);
+        } else if (FUSE1 && k == NPA + 1) {
+            const char* xs = rows_of(t, sidx);
 #pragma unroll
             for (int i = 0; i < XPD; ++i) {
                 const unsigned d = (unsigned)tid + (unsigned)i * NTHR;
@@ -704,11 +772,24 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             }
         }
     };
+    // RC1: this wave's W1 fragments (the same KS1 KiB every tile, L2-resident).  Fetched at the end of the previous tile --
+    // register pressure is lowest there -- so that the layer-1 chain at the top of phase A does not start with an L2
+    // round trip (measured: +0.1 ms per 65,536 tiles when it did)
+    uint4 w1f[RC1 ? FT : 1][RC1 ? KS1 : 1];
+    auto load_w1 = [&]() {
+#pragma unroll
+        for (int i = 0; i < FT; ++i)
+#pragma unroll
+            for (int s1 = 0; s1 < KS1; ++s1) w1f[RC1 ? i : 0][RC1 ? s1 : 0] = ldg16(a.w1b + ((size_t)(w * FT + i) * KS1 + s1) * 64, lo16);
+    };
+    if constexpr (RC1) load_w1();
     auto tile_or_last = [&](int t) { return t < a.B ? t : a.B - 1; };
     int idx_next = 0;
     if ((int)blockIdx.x < a.B) {
-        prefetch((int)blockIdx.x, FUSE1 ? a.idx[(int)blockIdx.x >> a.tps_shift] : 0);
-        if (FUSE1) idx_next = a.idx[tile_or_last((int)blockIdx.x + a.nwg) >> a.tps_shift];
+        const int sidx0 = (FUSE1 || RC1) && !a.x_by_tile ? a.idx[(int)blockIdx.x >> a.tps_shift] : 0;
+        prefetch((int)blockIdx.x, sidx0);
+        if ((FUSE1 || RC1) && !a.x_by_tile) idx_next = a.idx[tile_or_last((int)blockIdx.x + a.nwg) >> a.tps_shift];
+        if constexpr (RC1) { load_xraw((int)blockIdx.x, __builtin_amdgcn_readfirstlane(sidx0)); store_xfrag(); }   // first tile: latency exposed once
     }
     __syncthreads();
 
@@ -724,6 +805,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         // per-tile opaque lane offset: every global address below is re-formed from it (SGPR base + this VGPR) instead
         // of being hoisted out of the tile loop as ~30 loop-invariant 64-bit per-lane pointers that then spill
         asm volatile("" : "+v"(lo16));
+        BF16_SWZ();
         const float4 dy = ndy;
 #pragma unroll
         for (int i = 0; i < (FUSE1 ? XPD : 0); ++i) {
@@ -747,6 +829,39 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
 #pragma unroll
         for (int q = 0; q < (SPREAD ? 2 : NRL); ++q) ring_load(q);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RC1) {
+            // H1 of this wave's feature tiles, recomputed exactly as the forward kernel computes it (bias in the accumulator,
+            // KS1 k-steps in order, leakyrelu, RNE pack) and laid into the H1 image.  Its own segment in front of the dZ2
+            // work: the W1 fragments (L2-resident; the partner wave covers their round trip) and the accumulator are dead
+            // again before the dZ2 registers come alive
+#pragma unroll
+            for (int i = 0; i < FT; ++i) {
+                const int ft = w * FT + i;
+                // LDS addresses re-formed from the per-tile opaque lane offset (hoisted out of the tile loop they spill)
+                const unsigned lds0 = (unsigned)(size_t)(PPO_LDS void*)smem_c;
+                const PPO_LDS f32x4* const b1l = (const PPO_LDS f32x4*)(size_t)(lds0 + (unsigned)C::oB1 + (unsigned)ft * 128u + ((lo16 >> 3) & 64u));
+                const PPO_LDS u32x4* const xfl = (const PPO_LDS u32x4*)(size_t)(lds0 + (unsigned)C::oXF + lo16);
+                f32x16 a1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b = b1l[q];
+                    a1[4 * q + 0] = b.x; a1[4 * q + 1] = b.y; a1[4 * q + 2] = b.z; a1[4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int s1 = 0; s1 < KS1; ++s1) {
+                    const u32x4 xb = xfl[s1 * 64];
+                    a1 = mfma_bf16(w1f[i][s1], make_uint4(xb.x, xb.y, xb.z, xb.w), a1);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] = lrelu_max(a1[r]);
+                uint4 h1p[2];
+                pack_tile(a1, h1p);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(imgH1 + wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw)) = make_uint2(dw(h1p[g >> 1], 2 * (g & 1)), dw(h1p[g >> 1], 2 * (g & 1) + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const uint32_t dy01 = pack_bf16(dy.x, dy.y), dy23 = pack_bf16(dy.z, dy.w);    // exact: dY is stored bf16-rounded
         if (w == 0 && h == 0) *reinterpret_cast<float4*>(sDY + j * 4) = dy;
         if (w == 0 && h == 0) { float4 t = sDB3[j]; t.x += dy.x; t.y += dy.y; t.z += dy.z; t.w += dy.w; sDB3[j] = t; }
@@ -778,7 +893,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                 const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
                 *reinterpret_cast<uint2*>(imgZ2 + off) = make_uint2(dw(zf[g >> 1], 2 * (g & 1)), dw(zf[g >> 1], 2 * (g & 1) + 1));
                 *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
-                *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[i][g >> 1], 2 * (g & 1)), dw(nh1[i][g >> 1], 2 * (g & 1) + 1));
+                if constexpr (!RC1) *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[RC1 ? 0 : i][g >> 1], 2 * (g & 1)), dw(nh1[RC1 ? 0 : i][g >> 1], 2 * (g & 1) + 1));
                 if constexpr (SPREAD) {
                     if (g < 2) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -796,10 +911,10 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A).  They
             // are issued BEHIND the streamed W2^T half: vmcnt retires in order, so the chain below waits only for
             // fragments that are older than these loads
-            static_assert(4 * FT + 2 <= NS, "one prefetch piece per k-step");
+            static_assert(NPIECE <= NS, "one prefetch piece per k-step");
             constexpr int PF_T0 = 0;
             const int pf_tile = tile_or_last(tile + a.nwg), pf_sidx = __builtin_amdgcn_readfirstlane(idx_next);
-            if (FUSE1) idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
+            if ((FUSE1 || RC1) && !a.x_by_tile) idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
             f32x16 acc[FT];
 #pragma unroll
             for (int i = 0; i < FT; ++i)
@@ -837,6 +952,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             asm volatile("" : "+v"(swl_a));
             const PPO_LDS u32x4* const swl = (const PPO_LDS u32x4*)(size_t)swl_a;
             uint4 bzq[DL], wlq[DL][FT];
+            BF16_SWZ();
             const char* const zrow = imgZ2 + wrow;
             const int zc0 = 8 * ((2 * h) ^ wsw), zc1 = 8 * ((2 * h + 1) ^ wsw);        // byte offsets of the two chunks for even s; odd s: ^ 32
             auto kstep = [&](int t) { return t < NSR ? t + NSL : t - NSR; };
@@ -865,13 +981,14 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
 #pragma unroll
                 for (int i = 0; i < FT; ++i) acc[i] = mfma_bf16(wv[i], bz, acc[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (t >= PF_T0 && t - PF_T0 < 4 * FT + 2) prefetch_piece(t - PF_T0, pf_tile, pf_sidx);   // harmless re-load behind the last tile
+                if (t >= PF_T0 && t - PF_T0 < NPIECE) prefetch_piece(t - PF_T0, pf_tile, pf_sidx);   // harmless re-load behind the last tile
                 __builtin_amdgcn_sched_barrier(0);
             }
             BSTAMP(3);
 #pragma unroll
             for (int i = 0; i < FT; ++i) {
                 const int ft = w * FT + i;
+                BF16_SWZ();          // (shadows the chain's copies: those die with the chain)
                 uint2 hc[4];         // H1 of this feature tile, back from the image written in phase A (lane = row again)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) hc[g] = *reinterpret_cast<const uint2*>(imgH1 + wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw));
@@ -960,6 +1077,9 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             (void)emit_x;                                      // the dW1 kernel builds its X operands from the state rows itself
             }
         }
+        // layer-1 B operands of the NEXT tile (its state bytes were the first piece fetched during phase B) into sXF: read
+        // by everybody in that tile's phase A, behind the barrier below; this tile's readers are all past barrier 1
+        if constexpr (RC1) { store_xfrag(); load_w1(); }
         __syncthreads();
         BSTAMP(7);
     }
@@ -1123,6 +1243,7 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     a.idx = idx_dev; a.B = (int32_t)(B * tps);
     a.act1b = (const uint4*)p->act1.p; a.act2b = (const uint4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tb = (const uint4*)p->w2tb.p; a.w3tb = (const uint2*)p->w3tb.p;
+    a.w1b = (const uint4*)p->w1b.p; a.b1p = (const float4*)p->b1p.p;
     // the fp32 mode's activation buffers are twice the size the bf16 activations need: the operand fragments for the
     // dW1 kernel live in their upper halves (z1f behind act1b, xf behind act2b; NI <= NT)
     a.z1f = (uint4*)p->act1.p + (size_t)a.B * (p->HID / 32) * 128;

@@ -5,6 +5,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$1; rm -rf $O; mkdir -p $O
 timeout -k 10 600 python3 -m pytest tests/test_gpu_bf16.py -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; tail -5 $O/gpu_tests.log; echo "tests rc=$rc"
 [ $rc -eq 0 ] || exit $rc
+for tv in $3; do   # the same tests on variant libraries
+  PPO_HIP_LIB=$PWD/proximalpolicyoptimization.jl_amd/libppo_hip_$tv.so timeout -k 10 600 python3 -m pytest tests/test_gpu_bf16.py -m gpu -x -q > $O/gpu_tests_$tv.log 2>&1; rc=$?; tail -3 $O/gpu_tests_$tv.log; echo "tests($tv) rc=$rc"
+  [ $rc -eq 0 ] || exit $rc
+done
 for rep in 1 2; do for v in $2; do
   if [ "$v" = default ]; then unset PPO_HIP_LIB; else export PPO_HIP_LIB=$PWD/proximalpolicyoptimization.jl_amd/libppo_hip_$v.so; fi
   for e in 4096 65536; do
