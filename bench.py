@@ -410,9 +410,13 @@ def main():
                     # TRUE minimum of the backward per launch: per 32-row tile the two saved activation tiles, the state
                     # rows and dY in (fp32: 4 B, bf16: 2 B per activation), ONE gradient out.  The per-workgroup gradient
                     # slabs (written here, re-read by the reduction) are design traffic and listed separately.
-                    "algorithmic_hbm_bytes_per_launch": tiles * (2 * HID * 32 * (4 if args.dtype == "f32" else 2) + 32 * F + 32 * 16)
+                    # (bf16 mode: ONE saved tile -- the kernel recomputes H1 from the state rows; what it hands to the dW1
+                    # kernel at HID = 256, dZ1^T as bf16 fragments, is design traffic too)
+                    "algorithmic_hbm_bytes_per_launch": tiles * ((2 * HID * 32 * 4 if args.dtype == "f32" else HID * 32 * 2) + 32 * F + 32 * 16)
                     + 4 * (HID * HID + HID * F + HID * 6 + 4),
-                    "design_hbm_bytes_per_launch": {"gradient_slabs_written": min(256, tiles) * 4 * (HID * HID + HID * 96 + HID * 6 + 4)}}
+                    "design_hbm_bytes_per_launch": dict(
+                        {"gradient_slabs_written": min(256 if (HID == 256 or args.dtype == "bf16") else 512, tiles) * 4 * (HID * HID + HID * 96 + HID * 6 + 4)},
+                        **({"dz1_fragments_written": tiles * HID * 32 * 2} if args.dtype == "bf16" and HID > 128 else {}))}
     elif use_dist:
         iteration(args.warmup + args.steps)          # keep the collectives of the extra iteration matched
         PPO.synchronize()

@@ -30,4 +30,24 @@ if rows:
                        "PPO_BENCH_FORCE_DIST=1 bench.py --envs E (one-rank in-library RCCL all-reduce per optimiser step)",
                "shards": rows}, open("profiles/r02_strong_shards.json", "w"), indent=1)
 PY
+# the non-headline bench lines read roofline.traffic from profiles/r02_pmc_traffic.json AS IT WAS when they ran (part B runs
+# before this copy): refresh the field from the PMC passes of this same bundle
+python3 - <<'PY'
+import json, re
+pm = json.load(open("profiles/r02_pmc_traffic.json"))["launch_shapes"]
+for n in ("r02_bench_bf16.json", "r02_bench_bf16_65536envs.json", "r02_bench_config4_shape_8192envs.json", "r02_bench_hid128.json"):
+    p = "profiles/" + n
+    try: lines = open(p).read().strip().splitlines()
+    except FileNotFoundError: continue
+    d = json.loads(lines[-1])
+    src = d["roofline"].get("traffic_source") or ""
+    m = re.search(r"\[([^\]]+)\]", src)
+    key = m.group(1) if m else None
+    ent = pm.get(key) if key else None
+    if ent:
+        d["roofline"]["traffic"] = ent["k_policy_bwd_hbm_bytes"]
+        lines[-1] = json.dumps(d)
+        open(p, "w").write("\n".join(lines) + "\n")
+        print("refreshed", n, key, d["roofline"]["traffic"])
+PY
 ls -la profiles | grep r02
