@@ -16,8 +16,11 @@
 #include <mutex>
 #include <thread>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <dirent.h>
+#include <fcntl.h>
 #include <unistd.h>
+#include <cstdlib>
 
 struct DiskHeader { char magic[4]; uint32_t version; int64_t N; int32_t H, F, A, V; int64_t T; };
 
@@ -34,6 +37,7 @@ struct DiskSink {
     std::mutex mu;
     std::condition_variable cv;
     int64_t enq = 0, written = 0;         // records handed to the copy stream / written to the file
+    int batch = 1;                        // records per writev()
     bool stop = false, failed = false;
 };
 
@@ -75,21 +79,40 @@ static int rm_rf(const std::string& path) {
     return unlink(path.c_str());
 }
 
+// One writer thread, one append-only file.  It takes EVERY record that is ready in one writev() (up to half the ring):
+// the file system's per-call work (inode lock, size extension, extent bookkeeping) is paid once per batch instead of once
+// per 5 MB record -- a 152 MB expanded record went out at 9.8 GB/s where the 5.3 MB compact ones managed 4.4 GB/s.
+static bool write_all(int fd, struct iovec* iov, int n) {
+    while (n > 0) {
+        ssize_t w = writev(fd, iov, n);
+        if (w < 0) return false;
+        while (n > 0 && (size_t)w >= iov->iov_len) { w -= (ssize_t)iov->iov_len; ++iov; --n; }
+        if (n > 0 && w > 0) { iov->iov_base = (char*)iov->iov_base + w; iov->iov_len -= (size_t)w; }
+    }
+    return true;
+}
 static void writer_loop(DiskSink* s) {
+    const int fd = fileno(s->f);
+    const int maxb = s->batch > 0 ? s->batch : 1;
+    std::vector<struct iovec> iov((size_t)maxb);
     for (;;) {
-        int64_t k;
+        int64_t k, avail;
         {
             std::unique_lock<std::mutex> lk(s->mu);
             s->cv.wait(lk, [&] { return s->stop || s->written < s->enq; });
             if (s->written >= s->enq) { if (s->stop) return; continue; }
-            k = s->written;
+            k = s->written; avail = s->enq - s->written;
         }
-        const int slot = (int)(k % s->slots);
-        if (hipEventSynchronize(s->copied[slot]) != hipSuccess) s->failed = true;     // D2H of this record landed
-        if (!s->failed && fwrite(s->pinned[slot], 1, s->rec_bytes, s->f) != s->rec_bytes) s->failed = true;
+        const int nb = (int)std::min<int64_t>(avail, maxb);
+        for (int i = 0; i < nb; ++i) {
+            const int slot = (int)((k + i) % s->slots);
+            if (hipEventSynchronize(s->copied[slot]) != hipSuccess) s->failed = true;     // D2H of this record landed
+            iov[(size_t)i].iov_base = s->pinned[slot]; iov[(size_t)i].iov_len = s->rec_bytes;
+        }
+        if (!s->failed && !write_all(fd, iov.data(), nb)) s->failed = true;
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            s->written = k + 1;
+            s->written = k + nb;
         }
         s->cv.notify_all();
     }
@@ -175,7 +198,13 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     if (!s->f) { ppo_set_error("DiskRollouts: cannot open " + path); return PPO_ERR_ARG; }
     DiskHeader h;
     memcpy(h.magic, "PPOR", 4); h.version = ro->compact ? 2 : 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.V = ro->V; h.T = T;
-    if (fwrite(&h, sizeof(h), 1, s->f) != 1) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
+    if (fwrite(&h, sizeof(h), 1, s->f) != 1 || fflush(s->f) != 0) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
+    // records go out through the descriptor (writev), the returns column and the close through the FILE again: the stream is
+    // flushed here and holds nothing in between.  Blocks reserved up front where the file system can (no per-call
+    // allocation; KEEP_SIZE: the file still grows by appending, a short collection leaves no zero tail)
+    (void)fallocate(fileno(s->f), FALLOC_FL_KEEP_SIZE, 0, (off_t)(sizeof(h) + (size_t)T * rec + (size_t)T * ro->N * 4));
+    s->batch = std::max(1, s->slots / 2);
+    if (const char* e = getenv("PPO_DISK_BATCH")) s->batch = std::max(1, std::min(s->slots, atoi(e)));
     s->writer = std::thread(writer_loop, s);
     return PPO_OK;
 }
@@ -221,7 +250,7 @@ int32_t disk_sink_finish(ppo_rollouts_s* ro) {
     std::vector<float> ret(n);
     HIP_TRY(hipMemcpyAsync(ret.data(), ro->returns.p, n * 4, hipMemcpyDeviceToHost, ppo_stream()));
     HIP_TRY(hipStreamSynchronize(ppo_stream()));
-    if (fwrite(ret.data(), 4, n, s->f) != n) { ppo_set_error("DiskRollouts: returns write failed"); return PPO_ERR_ARG; }
+    if (fseek(s->f, 0, SEEK_END) != 0 || fwrite(ret.data(), 4, n, s->f) != n) { ppo_set_error("DiskRollouts: returns write failed"); return PPO_ERR_ARG; }
     fclose(s->f); s->f = nullptr;
     return PPO_OK;
 }
