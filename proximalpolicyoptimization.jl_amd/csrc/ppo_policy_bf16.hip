@@ -313,8 +313,7 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
                         if (g + PF1 < NG) ring[g % PF1] = wp[(size_t)(g + PF1) * 64];
                         acc = mfma_bf16(wv, xs[s], acc);
                     }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
+                    lrelu16(acc);
                     pack_tile(acc, h1p[o]);
                     if (TRAIN && !PPO_BF16_STORE_LATE && a.act1b) {
                         act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
@@ -352,8 +351,7 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
                     acc = mfma_bf16(wo[(2 * t) * 64], h1p[t][0], acc);
                     acc = mfma_bf16(wo[(2 * t + 1) * 64], h1p[t][1], acc);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = lrelu_max(acc[r]);
+                lrelu16(acc);
                 uint4 h2p[2];
                 pack_tile(acc, h2p);
                 if (TRAIN) {
@@ -852,8 +850,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                     const u32x4 xb = xfl[s1 * 64];
                     a1 = mfma_bf16(w1f[i][s1], make_uint4(xb.x, xb.y, xb.z, xb.w), a1);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[r] = lrelu_max(a1[r]);
+                lrelu16(a1);
                 uint4 h1p[2];
                 pack_tile(a1, h1p);
 #pragma unroll

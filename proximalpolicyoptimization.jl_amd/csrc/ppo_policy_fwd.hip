@@ -261,8 +261,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     // the epilogue reads the tile with VALU instructions: ask for VGPRs (hipcc otherwise parks the
                     // accumulator in AGPRs and copies it out with 16 v_accvgpr_read per tile)
                     asm volatile("" : "+v"(acc));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                    lrelu16(acc);
                     h1[o] = acc;
                     if (TRAIN && PPO_FWD_STORE) {
                         float4* dst = a.act1 + ((size_t)tile * NT + o) * 4 * 64;
@@ -311,8 +310,7 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
                     }
                     FSTAMP(2);
                     asm volatile("" : "+v"(acc));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                    lrelu16(acc);
                     if (TRAIN && PPO_FWD_STORE) {
                         float4* dst = a.act2 + ((size_t)tile * NT + o) * 4 * 64;
 #pragma unroll

@@ -113,8 +113,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_fwd_train_split(FwdArgs a) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xf[4 * s4 + 3], acc, 0, 0, 0);
                 }
                 asm volatile("" : "+v"(acc));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                lrelu16(acc);
                 float4* dst = a.act1 + ((size_t)state * NT + o) * 4 * 64;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -166,8 +165,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_fwd_train_split(FwdArgs a) {
                     }
                 }
                 asm volatile("" : "+v"(acc));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                lrelu16(acc);
                 float4* dst = a.act2 + ((size_t)state * NT + o) * 4 * 64;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, xf[4 * s4 + 3], acc, 0, 0, 0);
                     }
                     asm volatile("" : "+v"(acc));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                    lrelu16(acc);
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         sH[((grp * NT + o) * 4 + q) * 64 + lane] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -177,8 +176,7 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
                         }
                     }
                     asm volatile("" : "+v"(acc));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = lrelu(acc[r]);
+                    lrelu16(acc);
                     h2[oo] = acc;
                 }
             }
