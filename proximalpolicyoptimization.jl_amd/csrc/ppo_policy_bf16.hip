@@ -102,6 +102,9 @@ __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? 
 // ================================================================ forward
 // waves per forward workgroup (one workgroup per CU: W2 takes 128 KiB of its LDS): 8 = two per SIMD with 256 registers,
 // 12 = three per SIMD with 168
+#ifndef PPO_BF16_FWD_WQ
+#define PPO_BF16_FWD_WQ 4             // W2 fragments in flight (LDS -> registers) ahead of the layer-2 MFMAs
+#endif
 #ifndef PPO_BF16_FWD_WAVES
 #define PPO_BF16_FWD_WAVES 8
 #endif
@@ -337,6 +340,14 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
             f32x16 acc3;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[r] = 0.0f;
+            // W2 fragments are read from LDS WQ k-steps ahead of their MFMAs through an explicit queue that runs across the
+            // feature tiles (left alone hipcc keeps two fragments in flight and waits for each one a single 32-clock MFMA
+            // after issuing its read; sched_barrier pins the order).  The last tile's look-ahead reads the first
+            // fragments of what follows W2 in LDS (W3 / bias packs: in bounds, never used).
+            constexpr int WQ = (MODE == 4 && TPS == 4) ? 2 : PPO_BF16_FWD_WQ;      // (that instantiation has no registers to spare)
+            uint4 wq[WQ];
+#pragma unroll
+            for (int k = 0; k < WQ; ++k) wq[k] = sW2[k * 64 + lane];
 #pragma unroll 1
             for (int o = 0; o < NT; ++o) {
                 f32x16 acc;
@@ -346,10 +357,14 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
                     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                 }
                 const uint4* wo = sW2 + (size_t)o * NS * 64 + lane;
+                static_assert(NS % WQ == 0, "queue slots line up across feature tiles");
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc = mfma_bf16(wo[(2 * t) * 64], h1p[t][0], acc);
-                    acc = mfma_bf16(wo[(2 * t + 1) * 64], h1p[t][1], acc);
+                for (int k = 0; k < NS; ++k) {
+                    const uint4 wv = wq[k % WQ];
+                    wq[k % WQ] = wo[(k + WQ) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = mfma_bf16(wv, h1p[k >> 1][k & 1], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 lrelu16(acc);
                 uint4 h2p[2];
@@ -442,7 +457,8 @@ static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B
 #define LAUNCHB(FF, HH, TT)                                                                                          \
     do {                                                                                                             \
         /* MODE 4: one env-snapshot slot per wave + the template rows behind them */                               \
-        const size_t lds = FwdB<FF, HH>::lds_bytes + (MODE == 4 ? (size_t)FWB_W * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
+        /* + the W2 queue's look-ahead past the last feature tile (the persistent form's env slots cover it there) */ \
+        const size_t lds = FwdB<FF, HH>::lds_bytes + PPO_BF16_FWD_WQ * 1024 + (MODE == 4 ? (size_t)FWB_W * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
         static size_t attr_lds = 0;                                                                                  \
         if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<FF, HH, MODE, TT>,                            \
@@ -472,8 +488,11 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
     const size_t env_bytes = (size_t)FWB_W * slots * (2 * V + 32) + 32 * PPO_TPL;  // env slots + the template rows
 #define LAUNCHP(HH, TT)                                                                                              \
     do {                                                                                                             \
-        const size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                      \
+        /* the W2 queue's look-ahead past the last feature tile needs PPO_BF16_FWD_WQ KiB behind W2: env slots cover it, */ \
+        /* few of them are topped up */                                                                              \
+        size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                            \
         if (lds > 160 * 1024) return PPO_ERR_UNSUPPORTED;                                                            \
+        lds = std::max(lds, (size_t)FwdB<72, HH>::W2_U4 * 16 + PPO_BF16_FWD_WQ * 1024);                              \
         static size_t attr_lds = 0;                                                                                  \
         if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<72, HH, 3, TT>,                               \
