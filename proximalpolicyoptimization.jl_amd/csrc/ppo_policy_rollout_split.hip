@@ -211,14 +211,18 @@ __global__ __launch_bounds__(256, 1) void k_rollout_split(FwdArgs a) {
                 if (ENV) {
                 asm volatile("" ::: "memory");
                 float rew; uint8_t dn;
-                const int errf = env_step_wave32(ec, er, sampled, lane, rew, dn);
+                // (an opaque copy of the lane id: the env update's lane constants -- vertex, array, quad -- are then
+                // recomputed here instead of being hoisted out of the step loop as registers that spill)
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int errf = env_step_wave32(ec, er, sampled, lane_e, rew, dn);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) {
                     a.active_out[out_index] = act;
                     if (errf) atomicOr(a.err, errf);
                     a.rew_out[out_index] = rew; a.done_out[out_index] = dn;
                 }
-                if (dn) env_reset_wave32(ec, er, (uint32_t)(a.global_offset + state), lane);
+                if (dn) env_reset_wave32(ec, er, (uint32_t)(a.global_offset + state), lane_e);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
             }
