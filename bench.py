@@ -236,6 +236,9 @@ def main():
                     help="f32 = BASELINE configs[1] (the headline line); bf16 = the config-5 arithmetic on the same workload "
                          "(flagged in the output, not the headline)")
     ap.add_argument("--envs", type=int, default=N_ENVS, help="envs per GPU (default 4096 = the headline workload)")
+    ap.add_argument("--stream", metavar="DIR", default=None,
+                    help="stream every rollout to DIR/rollout.bin while it is collected (DiskRollouts: device -> pinned host -> "
+                         "file; BASELINE config 5 'rollouts streamed to disk'); training reads the resident copy.  Not the headline")
     ap.add_argument("--hid", type=int, choices=[128, 256], default=HID,
                     help="hidden width: 256 = the headline 2x256 MLP, 128 = the reference's own Policy(72,128,2,4) (not the headline)")
     ap.add_argument("--quads", type=int, choices=[8, 32], default=QUADS,
@@ -247,7 +250,7 @@ def main():
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
-    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS) or (args.hid != HID)
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS) or (args.hid != HID) or bool(args.stream)
     HID = args.hid
     QUADS = args.quads
     N_ENVS = MINIBATCH = args.envs
@@ -319,8 +322,13 @@ def main():
         ro = PPO.BufferRollouts()
 
         def iteration(i):
-            PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
-            ds = PPO.construct_dataset(ro)
+            if args.stream:                              # a fresh DiskRollouts per iteration, as src/train.jl:185 does
+                dro = PPO.DiskRollouts(os.path.join(args.stream, "rank%d" % rank))
+                PPO.collect_rollouts_steps_(dro, env, pol, T_STEPS, GAMMA)
+                ds = PPO.construct_dataset(dro._device)
+            else:
+                PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
+                ds = PPO.construct_dataset(ro)
             PPO.ppo_train_(pol, opt, ds, EPS, minibatch, EPOCHS, ENT_W, seed=seed_base + i, parallel=dp, verbose=False)
 
         for i in range(args.warmup):
@@ -448,7 +456,8 @@ def main():
                                    % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, HID, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "rollouts_streamed_to_disk": bool(args.stream)},
             "allreduce": (dp.hook_kind if use_dist else None), "rccl_ranks": (comm[1] if comm else None),
             "strong": strong,
             "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced, "headline_config": not nonheadline,

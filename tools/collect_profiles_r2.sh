@@ -8,6 +8,7 @@ cp $F/pmc_summary.txt profiles/r02_pmc_summary.txt
 cp $F/pmc_traffic.json profiles/r02_pmc_traffic.json
 [ -f $F/bench_bf16.json ] && cp $F/bench_bf16.json profiles/r02_bench_bf16.json
 [ -f $F/bench_bf16_c5.json ] && cp $F/bench_bf16_c5.json profiles/r02_bench_bf16_65536envs.json
+[ -f $F/bench_bf16_c5_streamed.json ] && cp $F/bench_bf16_c5_streamed.json profiles/r02_bench_bf16_65536envs_streamed.json
 [ -f $F/bench_c4.json ] && cp $F/bench_c4.json profiles/r02_bench_config4_shape_8192envs.json
 [ -f $F/bench_h128.json ] && cp $F/bench_h128.json profiles/r02_bench_hid128.json
 ls $F/trace_bf16/*/*kernel_stats.csv >/dev/null 2>&1 && cp $(ls -t $F/trace_bf16/*/*kernel_stats.csv | head -1) profiles/r02_rocprof_kernel_stats_bf16.csv
@@ -35,7 +36,7 @@ PY
 python3 - <<'PY'
 import json, re
 pm = json.load(open("profiles/r02_pmc_traffic.json"))["launch_shapes"]
-for n in ("r02_bench_bf16.json", "r02_bench_bf16_65536envs.json", "r02_bench_config4_shape_8192envs.json", "r02_bench_hid128.json"):
+for n in ("r02_bench_bf16.json", "r02_bench_bf16_65536envs.json", "r02_bench_bf16_65536envs_streamed.json", "r02_bench_config4_shape_8192envs.json", "r02_bench_hid128.json"):
     p = "profiles/" + n
     try: lines = open(p).read().strip().splitlines()
     except FileNotFoundError: continue

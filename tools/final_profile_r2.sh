@@ -31,6 +31,8 @@ else
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $F/trace_bf16 -- $B --steps 2 --warmup 1 --dtype bf16 > $F/trace_bf16.log 2>&1 || { tail -5 $F/trace_bf16.log; exit 1; }
   rm -f $F/trace_bf16/*/*kernel_trace.csv
   timeout -k 10 300 $B --steps 1 --warmup 1 --dtype bf16 --envs 65536 > $F/bench_bf16_c5.json 2> $F/bench_bf16_c5.err || { tail -5 $F/bench_bf16_c5.err; exit 1; }
+  timeout -k 10 300 $B --steps 1 --warmup 1 --dtype bf16 --envs 65536 --stream /tmp/ppo_bench_stream > $F/bench_bf16_c5_streamed.json 2> $F/bench_bf16_c5_streamed.err || { tail -5 $F/bench_bf16_c5_streamed.err; exit 1; }
+  rm -rf /tmp/ppo_bench_stream
   timeout -k 10 300 $B --steps 3 --warmup 1 --quads 32 --envs 8192 > $F/bench_c4.json 2> $F/bench_c4.err || { tail -5 $F/bench_c4.err; exit 1; }
   timeout -k 10 300 $B --steps 3 --warmup 1 --hid 128 > $F/bench_h128.json 2> $F/bench_h128.err || { tail -5 $F/bench_h128.err; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $F/trace_h128 -- $B --steps 2 --warmup 1 --hid 128 > $F/trace_h128.log 2>&1 || { tail -5 $F/trace_h128.log; exit 1; }
