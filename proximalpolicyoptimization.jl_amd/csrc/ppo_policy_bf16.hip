@@ -55,6 +55,13 @@
 #ifndef PPO_BF16_H1_RECOMPUTE
 #define PPO_BF16_H1_RECOMPUTE 1
 #endif
+// Where dW1 is NOT accumulated in the backward kernel (HID = 256), the two wave-private transposes -- H2 for the dW3 sums,
+// dZ1 for the fragments handed to k_policy_dw1_bf16 -- run as identity MFMAs on the (70 % idle) matrix pipe instead of an LDS
+// image write + transposed read: D = P * I puts the rows of the lane-is-row fragment P on the accumulator registers of
+// the lane that owns the feature.  No H2 / dZ1 image: 18 KB of LDS back (two more resident W2^T k-steps).
+#ifndef PPO_BF16_MFMA_TRANSPOSE
+#define PPO_BF16_MFMA_TRANSPOSE 1
+#endif
 #ifndef PPO_BF16_BWD_DL8
 #define PPO_BF16_BWD_DL8 2            // LDS operand queue depth of the dH1 chain in the 8-wave form (the partner wave covers the rest)
 #endif
@@ -564,12 +571,13 @@ struct BwdB {
     static constexpr int IMG = 32 * ST;
     // k-steps of W2^T resident in LDS for the whole launch (the rest streams from L2 once per tile into a register ring):
     // three images (dZ1 reuses the H2 image, see phase B) + the X image leave room for 12 of the 16 at HID = 256
-    static constexpr int NSL = (HID >= 256) ? 12 : NS, NSR = NS - NSL;
-    static constexpr int oZ2 = 0, oH1 = IMG, oH2 = 2 * IMG, oX = 3 * IMG,
-                         oDY = oX + 32 * STX, oDB3 = oDY + 512, oB1 = oDB3 + 512, oW = oB1 + NT * 128,
-                         wEnd = oW + NT * NSL * 1024;
-    static constexpr int KS1 = (F + 15) / 16;             // layer-1 k-steps
     static constexpr bool FUSE = (HID <= PPO_BF16_DW1_FUSED_MAX_HID);
+    static constexpr bool TRN = PPO_BF16_MFMA_TRANSPOSE && !FUSE;       // identity-MFMA transposes, no H2 / dZ1 image
+    static constexpr int NSL = (HID >= 256) ? (TRN ? 14 : 12) : NS, NSR = NS - NSL;
+    static constexpr int oZ2 = 0, oH1 = IMG, oH2 = 2 * IMG, oX = TRN ? 2 * IMG : 3 * IMG,
+                         oDY = oX + 32 * STX, oDB3 = oDY + 512, oB1 = oDB3 + 512, oID = oB1 + NT * 128,
+                         oW = oID + (TRN ? 2048 : 0), wEnd = oW + NT * NSL * 1024;
+    static constexpr int KS1 = (F + 15) / 16;             // layer-1 k-steps
     // layer-1 B operands (X as bf16 fragments, KS1 KiB) of the tile about to be processed: where the X image would be
     // when dW1 is not accumulated here, behind the weights otherwise
     static constexpr int oXF = FUSE ? wEnd : oX, total = FUSE ? wEnd + (KS1 + 1) * 1024 : wEnd;     // + one spare slot
@@ -635,6 +643,23 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (RC1) for (int i = tid; i < NT * 8; i += C::NW * 64) sB1[i] = a.b1p[i];
+    constexpr bool TRN = C::TRN;
+    // identity B operands of the transposing MFMAs: k-slot (step s, lane half hB, element e) carries feature
+    // 16s + 8(e>>2) + 4hB + (e&3) of the packed fragment, so lane (n, hB) holds a single 1.0 -- in step n>>4, element
+    // 4((n>>3)&1) + (n&3), and only if hB == (n>>2)&1
+    u32x4* const sID = reinterpret_cast<u32x4*>(smem_c + C::oID);
+    if (TRN && tid < 64) {
+        const int n = tid & 31, hB = tid >> 5, e = 4 * ((n >> 3) & 1) + (n & 3);
+#pragma unroll
+        for (int s1 = 0; s1 < 2; ++s1) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (hB == ((n >> 2) & 1) && s1 == (n >> 4)) {
+                const uint32_t one = (e & 1) ? 0x3F800000u : 0x00003F80u;
+                if ((e >> 1) == 0) v.x = one; else if ((e >> 1) == 1) v.y = one; else if ((e >> 1) == 2) v.z = one; else v.w = one;
+            }
+            sID[s1 * 64 + tid] = v;
+        }
+    }
 
     // k-steps 0 .. NSL-1 of this wave's W2^T fragments stay in LDS for the whole launch (all that is left of the 160 KiB
     // next to the images); the other NSR stream from L2 once per tile, issued through phase A, so the dH1 chain of
@@ -912,7 +937,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             for (int g = 0; g < 4; ++g) {
                 const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
                 *reinterpret_cast<uint2*>(imgZ2 + off) = make_uint2(dw(zf[g >> 1], 2 * (g & 1)), dw(zf[g >> 1], 2 * (g & 1) + 1));
-                *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
+                if constexpr (!TRN) *reinterpret_cast<uint2*>(imgH2 + off) = make_uint2(dw(nh2[i][g >> 1], 2 * (g & 1)), dw(nh2[i][g >> 1], 2 * (g & 1) + 1));
                 if constexpr (!RC1) *reinterpret_cast<uint2*>(imgH1 + off) = make_uint2(dw(nh1[RC1 ? 0 : i][g >> 1], 2 * (g & 1)), dw(nh1[RC1 ? 0 : i][g >> 1], 2 * (g & 1) + 1));
                 if constexpr (SPREAD) {
                     if (g < 2) {
@@ -943,6 +968,28 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             // dW3[o][f] = sum_rows dY[row][o] H2[row][f] on the VALU (4 accumulators per lane instead of a 16-register
             // MFMA tile that would be 7/8 zero padding): lane (f, h) holds rows 16s + 8h + e of column f.  Done HERE, in
             // front of the chain: afterwards this wave's columns of the H2 image are free and take dZ1 (epilogue below)
+            if constexpr (TRN) {
+                // H2 of the wave's feature tiles is still in the registers it was prefetched into (lane = row): two identity
+                // MFMAs turn it (D[row][feature] = sum_slot P[row][slot] I[slot][feature]): lane (feature, h) then holds rows
+                // (r&3) + 8(r>>2) + 4h in accumulator register r, as exact fp32 copies of the bf16 values
+                const unsigned lds0 = (unsigned)(size_t)(PPO_LDS void*)smem_c;
+                const PPO_LDS u32x4* const idl = (const PPO_LDS u32x4*)(size_t)(lds0 + (unsigned)C::oID + lo16);
+                const u32x4 i0 = idl[0], i1 = idl[64];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+                    d = mfma_bf16(nh2[i][0], make_uint4(i0.x, i0.y, i0.z, i0.w), d);
+                    d = mfma_bf16(nh2[i][1], make_uint4(i1.x, i1.y, i1.z, i1.w), d);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 y = *reinterpret_cast<const float4*>(sDY + ((r & 3) + 8 * (r >> 2) + 4 * h) * 4);
+                        dw3[i][0] = fmaf(y.x, d[r], dw3[i][0]); dw3[i][1] = fmaf(y.y, d[r], dw3[i][1]);
+                        dw3[i][2] = fmaf(y.z, d[r], dw3[i][2]); dw3[i][3] = fmaf(y.w, d[r], dw3[i][3]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -957,6 +1004,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                         dw3[i][2] = fmaf(y.z, hv, dw3[i][2]); dw3[i][3] = fmaf(y.w, hv, dw3[i][3]);
                     }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
             // The k-steps whose W2^T fragments were streamed into registers run first (their registers free up), then
             // the LDS-resident ones.  LDS operands are read DL steps ahead of their MFMAs (explicit queue; sched_barrier
@@ -1019,10 +1067,31 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                 }
                 uint4 z1[2];
                 pack_tile(acc[i], z1);
+                if constexpr (TRN) {
+                    // dZ1^T of this feature tile as the A-operand fragments of k_policy_dw1_bf16, by the same identity MFMAs:
+                    // lane (k, h) gets rows (r&3) + 8(r>>2) + 4h -- the dW1 kernel reads its X operands in that row order
+                    const unsigned lds0 = (unsigned)(size_t)(PPO_LDS void*)smem_c;
+                    const PPO_LDS u32x4* const idl = (const PPO_LDS u32x4*)(size_t)(lds0 + (unsigned)C::oID + lo16);
+                    const u32x4 i0 = idl[0], i1 = idl[64];
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+                    d = mfma_bf16(z1[0], make_uint4(i0.x, i0.y, i0.z, i0.w), d);
+                    d = mfma_bf16(z1[1], make_uint4(i1.x, i1.y, i1.z, i1.w), d);
+                    float sd = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sd += d[r];
+                    db1[i] += sd;
+                    uint4 zt[2];
+                    pack_tile(d, zt);
+                    stg16(a.z1f + (((size_t)tile * NT + ft) * 2 + 0) * 64, lo16, zt[0]);
+                    stg16(a.z1f + (((size_t)tile * NT + ft) * 2 + 1) * 64, lo16, zt[1]);
+                } else {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int off = wrow + 64 * ft + 8 * ((2 * g + h) ^ wsw);
                     *reinterpret_cast<uint2*>(imgZ1 + off) = make_uint2(dw(z1[g >> 1], 2 * (g & 1)), dw(z1[g >> 1], 2 * (g & 1) + 1));
+                }
                 }
             }
         }
@@ -1090,10 +1159,12 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             } else {
             // dZ1^T of this wave's feature tiles and (first NI slots) the X column tiles, as MFMA operand fragments
             // for k_policy_dw1_bf16
+            if constexpr (!TRN) {
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) emit_z(i, s);
+            }
             (void)emit_x;                                      // the dW1 kernel builds its X operands from the state rows itself
             }
         }
@@ -1178,7 +1249,8 @@ __global__ __launch_bounds__(HID * 2) void k_policy_dw1_bf16(BwdBArgs a) {
     const int tq = (lane & 15) >> 2, tcc = 4 * ((lane >> 4) & 1) + (lane & 3);
     int trx[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) trx[u] = (8 * h + 4 * u + tq) * STX + 8 * tcc;
+    for (int u = 0; u < 2; ++u)     // rows of k-slot element e: 8h + e in the natural order, (e&3) + 8(e>>2) + 4h behind the identity-MFMA transposes
+        trx[u] = (C::TRN ? (4 * h + 8 * u + tq) : (8 * h + 4 * u + tq)) * STX + 8 * tcc;
     int xw_off[XPD];                                             // image byte offset of this thread's 8 features
 #pragma unroll
     for (int i = 0; i < XPD; ++i) { const int u = tid + i * NTHR; xw_off[i] = (u / (F / 8)) * STX + (u % (F / 8)) * 16; }
