@@ -112,6 +112,12 @@ __device__ __forceinline__ uint32_t dw(const uint4& v, int i) { return i == 0 ? 
 #ifndef PPO_BF16_FWD_WQ
 #define PPO_BF16_FWD_WQ 4             // W2 fragments in flight (LDS -> registers) ahead of the layer-2 MFMAs
 #endif
+// layer-2 epilogues software-pipelined into the next feature tile's MFMA chain: 1 = where the second accumulator costs at
+// most 4 registers of scratch (every H = 32 instantiation -- the persistent rollout and the compact-source forward spill
+// 16 bytes and still gain 4-6 % -- and the H = 128 ones without a loss tail), 2 = everywhere (A/B), 0 = off
+#ifndef PPO_BF16_FWD_PIPE
+#define PPO_BF16_FWD_PIPE 1
+#endif
 #ifndef PPO_BF16_FWD_WAVES
 #define PPO_BF16_FWD_WAVES 8
 #endif
@@ -308,28 +314,66 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
                 uint4 ring[PF1];
 #pragma unroll
                 for (int g = 0; g < PF1; ++g) ring[g] = wp[(size_t)g * 64];
-#pragma unroll
-                for (int o = 0; o < NT; ++o) {
-                    f32x16 acc;
+                auto bias1 = [&](f32x16& acc, int o) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 b = sB1[(o * 2 + h) * 4 + q];
                         acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                     }
+                };
+                auto step1 = [&](f32x16& acc, int o, int s) {
+                    const int g = o * KS1 + s;
+                    const uint4 wv = ring[g % PF1];
+                    if (g + PF1 < NG) ring[g % PF1] = wp[(size_t)(g + PF1) * 64];
+                    acc = mfma_bf16(wv, xs[s], acc);
+                };
+                // a quarter of a tile's epilogue: leakyrelu + RNE pack of accumulator registers 4p .. 4p+3 -> two dwords of
+                // the next layer's B operand (same values and order as lrelu16 + pack_tile)
+                auto epi1 = [&](f32x16& acc, int o, int p4) {
+                    const pk2f x0 = {acc[4 * p4], acc[4 * p4 + 1]}, x1 = {acc[4 * p4 + 2], acc[4 * p4 + 3]};
+                    const pk2f y0 = x0 * pk2f{0.01f, 0.01f}, y1 = x1 * pk2f{0.01f, 0.01f};
+                    float r0, r1, r2, r3;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(x0.x), "v"(y0.x));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x0.y), "v"(y0.y));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r2) : "v"(x1.x), "v"(y1.x));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r3) : "v"(x1.y), "v"(y1.y));
+                    const uint32_t d0 = pack_bf16(r0, r1), d1 = pack_bf16(r2, r3);
+                    if (p4 & 1) { h1p[o][p4 >> 1].z = d0; h1p[o][p4 >> 1].w = d1; }
+                    else        { h1p[o][p4 >> 1].x = d0; h1p[o][p4 >> 1].y = d1; }
+                };
+                static_assert(PPO_BF16_STORE_LATE, "the layer-1 stores leave behind the loop");
+                if constexpr (PPO_BF16_FWD_PIPE && KS1 >= 4) {
+                    // the epilogue of tile o in four pieces behind the first four MFMAs of tile o + 1 (a bf16 MFMA leaves the
+                    // vector ALU free for the 32 clocks it occupies the matrix pipe)
+                    f32x16 accs[2];
+                    bias1(accs[0], 0);
 #pragma unroll
-                    for (int s = 0; s < KS1; ++s) {
-                        const int g = o * KS1 + s;
-                        const uint4 wv = ring[g % PF1];
-                        if (g + PF1 < NG) ring[g % PF1] = wp[(size_t)(g + PF1) * 64];
-                        acc = mfma_bf16(wv, xs[s], acc);
-                    }
-                    lrelu16(acc);
-                    pack_tile(acc, h1p[o]);
-                    if (TRAIN && !PPO_BF16_STORE_LATE && a.act1b) {
-                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + lane, h1p[o][0]);
-                        act_store_nt_u4(a.act1b + ((size_t)tile * NT + o) * 128 + 64 + lane, h1p[o][1]);
-                    }
+                    for (int s = 0; s < KS1; ++s) step1(accs[0], 0, s);
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int o = 0; o + 1 < NT; ++o) {
+                        bias1(accs[(o + 1) & 1], o + 1);
+#pragma unroll
+                        for (int s = 0; s < KS1; ++s) {
+                            step1(accs[(o + 1) & 1], o + 1, s);
+                            if (s < 4) epi1(accs[o & 1], o, s);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) epi1(accs[(NT - 1) & 1], NT - 1, p4);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+#pragma unroll
+                for (int o = 0; o < NT; ++o) {
+                    f32x16 acc;
+                    bias1(acc, o);
+#pragma unroll
+                    for (int s = 0; s < KS1; ++s) step1(acc, o, s);
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) epi1(acc, o, p4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 // saved layer-1 activations leave AFTER the last W1 fragment has been waited for: loads and stores share
                 // the in-order vmcnt queue, so a store between two ring loads puts its HBM round trip on the MFMA chain
@@ -355,36 +399,79 @@ __global__ __launch_bounds__(FWB_T, (FWB_W / 4)) void k_policy_fwd_bf16(FwdArgs 
             uint4 wq[WQ];
 #pragma unroll
             for (int k = 0; k < WQ; ++k) wq[k] = sW2[k * 64 + lane];
-#pragma unroll 1
-            for (int o = 0; o < NT; ++o) {
-                f32x16 acc;
+            // One step of a feature tile's chain: k-step k of tile o into `acc` (queue slot refilled WQ steps ahead).
+            auto chain_step = [&](f32x16& acc, int o, int k) {
+                const uint4* wo = sW2 + (size_t)o * NS * 64 + lane;
+                const uint4 wv = wq[k % WQ];
+                wq[k % WQ] = wo[(k + WQ) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma_bf16(wv, h1p[k >> 1][k & 1], acc);
+            };
+            auto bias_init = [&](f32x16& acc, int o) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = sB2[(o * 2 + h) * 4 + q];
                     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
                 }
-                const uint4* wo = sW2 + (size_t)o * NS * 64 + lane;
-                static_assert(NS % WQ == 0, "queue slots line up across feature tiles");
+            };
+            // The epilogue of a feature tile (leakyrelu, RNE pack, activation store, the two layer-3 MFMAs) cut into 16
+            // slices, one per k-step of the NEXT tile's chain: a bf16 MFMA occupies the matrix pipe for 32 clocks and, unlike
+            // the fp32 one, leaves the vector ALU free, so a slice issued right behind an MFMA runs in its shadow.  Values and
+            // operation order per value are those of the one-piece epilogue.
+            uint32_t hp[8];                                       // the packed H2 tile being assembled (two B operands)
+            uint4 w3q;                                            // layer-3 A operand, read two slices ahead of its MFMA
+            auto epi_slice = [&](f32x16& acc, int o, int k) {
+                if (k & 1) {
+                    const pk2f x = {acc[k - 1], acc[k]};
+                    const pk2f y = x * pk2f{0.01f, 0.01f};
+                    float r0, r1;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(x.x), "v"(y.x));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(x.y), "v"(y.y));
+                    hp[k >> 1] = pack_bf16(r0, r1);
+                }
+                if (k == 5 || k == 13) {
+                    const int sh = k >> 3;
+                    const int idx = (w3_lane >= 0) ? ((2 * o + sh) * 8 + w3_lane) : NS * 8;
+                    w3q = sW3[idx];
+                }
+                if (k == 7 || k == 15) {
+                    const int sh = k >> 3;
+                    const uint4 hv = make_uint4(hp[4 * sh], hp[4 * sh + 1], hp[4 * sh + 2], hp[4 * sh + 3]);
+                    if (TRAIN) act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + 64 * sh + lane, hv);
+                    acc3 = mfma_bf16(w3q, hv, acc3);
+                }
+            };
+            // (one epilogue slice per k-step: the interleaved form needs 16 of each, i.e. HID = 256)
+            constexpr bool PIPE2 = PPO_BF16_FWD_PIPE && (NT % 2 == 0) && (NS == 16) && (TPS == 1 || MODE <= 1 || PPO_BF16_FWD_PIPE > 1);
+            if constexpr (PIPE2) {
+                f32x16 acc0, acc1;
+                bias_init(acc0, 0);
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const uint4 wv = wq[k % WQ];
-                    wq[k % WQ] = wo[(k + WQ) * 64];
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc = mfma_bf16(wv, h1p[k >> 1][k & 1], acc);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                lrelu16(acc);
-                uint4 h2p[2];
-                pack_tile(acc, h2p);
-                if (TRAIN) {
-                    act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + lane, h2p[0]);
-                    act_store_nt_u4(a.act2b + ((size_t)tile * NT + o) * 128 + 64 + lane, h2p[1]);
-                }
+                for (int k = 0; k < NS; ++k) { chain_step(acc0, 0, k); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll 1
+                for (int o = 0; o + 2 < NT; o += 2) {            // chains o+1, o+2 beside the epilogues of o, o+1
+                    bias_init(acc1, o + 1);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int idx = (w3_lane >= 0) ? ((2 * o + s) * 8 + w3_lane) : NS * 8;
-                    acc3 = mfma_bf16(sW3[idx], h2p[s], acc3);
+                    for (int k = 0; k < NS; ++k) { chain_step(acc1, o + 1, k); epi_slice(acc0, o, k); __builtin_amdgcn_sched_barrier(0); }
+                    bias_init(acc0, o + 2);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) { chain_step(acc0, o + 2, k); epi_slice(acc1, o + 1, k); __builtin_amdgcn_sched_barrier(0); }
                 }
+                bias_init(acc1, NT - 1);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { chain_step(acc1, NT - 1, k); epi_slice(acc0, NT - 2, k); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) epi_slice(acc1, NT - 1, k);
+            } else {
+#pragma unroll 1
+            for (int o = 0; o < NT; ++o) {
+                f32x16 acc;
+                bias_init(acc, o);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { chain_step(acc, o, k); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) epi_slice(acc, o, k);
+            }
             }
             FBSTAMP(3);
             // logits of row j sit in accumulator registers 0..3 of lane j (lane half 0): hand them to both halves
