@@ -1185,7 +1185,9 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         // a wave's dZ1 columns are read back (transposed) by that wave only: its own LDS writes just have to land.
         // Phase C writes no LDS, so the other waves' phase-B reads need no barrier here; the one at the end of the
         // tile keeps the next phase A from overwriting the images early.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (identity-MFMA form: no dZ1 image, nothing to wait for -- and without the wait hipcc may run the epilogue's vector
+        // work beside phase C's transposed reads and MFMAs)
+        if constexpr (!TRN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         BSTAMP(4);
         // ================= phase C: products that contract over the 32 rows (operands: transposed image reads)
         {
