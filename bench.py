@@ -365,6 +365,8 @@ def main():
             ms, n = PPO.profile_get(name)
             if n:
                 avg = ms / n
+                if name == "k_rollout_persistent":
+                    per = per / n                        # streamed to disk the rollout is a chain of launches, T / n steps each
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
                                  "frac": round(tf / peak, 4)}
