@@ -62,6 +62,13 @@
 #ifndef PPO_BF16_MFMA_TRANSPOSE
 #define PPO_BF16_MFMA_TRANSPOSE 1
 #endif
+// identity-MFMA form: the dH1 epilogue in front of phase C (0) or inside it, two accumulator registers behind the dW2 MFMAs
+// of each k-tile (1).  Measured 2 % SLOWER (0.940 -> 0.958 ms at 65,536 states, gpurun_out/r2b14, r2b15; with and without
+// scheduling pins): unlike the forward's chains, phase C already overlaps its transposed reads with its MFMAs, and
+// carrying the dH1 accumulator through it costs more than the vector work it hides.  Kept as an A/B switch.
+#ifndef PPO_BF16_BWD_EPI_IN_C
+#define PPO_BF16_BWD_EPI_IN_C 0
+#endif
 #ifndef PPO_BF16_BWD_DL8
 #define PPO_BF16_BWD_DL8 2            // LDS operand queue depth of the dH1 chain in the 8-wave form (the partner wave covers the rest)
 #endif
@@ -1039,6 +1046,8 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
         __syncthreads();
         BSTAMP(2);
         // ================= phase B: dH1^T[k-tiles of this wave] = W2^T dZ2^T, dZ1 = dH1 . lrelu'(H1) -> image
+        f32x16 accH[FT];                // dH1 of this wave's feature tiles (EPI_C: its epilogue runs inside phase C)
+        constexpr bool EPI_C = TRN && PPO_BF16_BWD_EPI_IN_C && (16 % NT == 0);
         {
             // the next tile's inputs start their HBM round trip here (their registers were consumed in phase A).  They
             // are issued BEHIND the streamed W2^T half: vmcnt retires in order, so the chain below waits only for
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             constexpr int PF_T0 = 0;
             const int pf_tile = tile_or_last(tile + a.nwg), pf_sidx = __builtin_amdgcn_readfirstlane(idx_next);
             if ((FUSE1 || RC1) && !a.x_by_tile) idx_next = a.idx[tile_or_last(tile + 2 * a.nwg) >> a.tps_shift];
-            f32x16 acc[FT];
+            auto& acc = accH;
 #pragma unroll
             for (int i = 0; i < FT; ++i)
 #pragma unroll
@@ -1141,7 +1150,7 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
             }
             BSTAMP(3);
 #pragma unroll
-            for (int i = 0; i < FT; ++i) {
+            for (int i = 0; i < (EPI_C ? 0 : FT); ++i) {
                 const int ft = w * FT + i;
                 BF16_SWZ();          // (shadows the chain's copies: those die with the chain)
                 uint2 hc[4];         // H1 of this feature tile, back from the image written in phase A (lane = row again)
@@ -1216,6 +1225,17 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                     az[i][s] = tr_frag(imgZ2 + tro[0] + 16 * s * ST + 64 * (w * FT + i), imgZ2 + tro[1] + 16 * s * ST + 64 * (w * FT + i));
                     db2[i] += sum_frag(az[i][s]);
                 }
+            // EPI_C: the dH1 epilogue (dZ1 = dH1 . lrelu'(H1), two accumulator registers per step) issues behind the dW2 MFMAs
+            // of each k-tile -- the chain that produced dH1 is done, the two are independent, and a bf16 MFMA leaves the
+            // vector ALU free for the 32 clocks it holds the matrix pipe
+            uint2 hcq[FT][4];
+            if constexpr (EPI_C) {
+                BF16_SWZ();
+#pragma unroll
+                for (int i = 0; i < FT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) hcq[i][g] = *reinterpret_cast<const uint2*>(imgH1 + wrow + 64 * (w * FT + i) + 8 * ((2 * g + h) ^ wsw));
+            }
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 uint4 b[2];
@@ -1225,6 +1245,42 @@ __global__ __launch_bounds__((BwdB<F, HID>::NW * 64), 1) void k_policy_bwd_bf16(
                 for (int i = 0; i < FT; ++i)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) accW2[i][kt] = mfma_bf16(az[i][s], b[s], accW2[i][kt]);
+                if constexpr (EPI_C) {
+                    constexpr int RPS = 16 / NT;
+#pragma unroll
+                    for (int i = 0; i < FT; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < RPS; ++rr) {
+                            const int r = RPS * kt + rr;
+                            const uint32_t d = (r & 2) ? hcq[i][r >> 2].y : hcq[i][r >> 2].x;
+                            accH[i][r] = accH[i][r] * ((r & 1) ? slope_hi(d) : slope_lo(d));
+                        }
+                }
+            }
+            if constexpr (EPI_C) {
+                // the rest of the epilogue: RNE pack, the identity-MFMA transpose, db1, the fragments for the dW1 kernel
+                const unsigned lds0 = (unsigned)(size_t)(PPO_LDS void*)smem_c;
+                const PPO_LDS u32x4* const idl = (const PPO_LDS u32x4*)(size_t)(lds0 + (unsigned)C::oID + lo16);
+                const u32x4 i0 = idl[0], i1 = idl[64];
+#pragma unroll
+                for (int i = 0; i < FT; ++i) {
+                    const int ft = w * FT + i;
+                    uint4 z1[2];
+                    pack_tile(accH[i], z1);
+                    f32x16 d;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) d[r] = 0.0f;
+                    d = mfma_bf16(z1[0], make_uint4(i0.x, i0.y, i0.z, i0.w), d);
+                    d = mfma_bf16(z1[1], make_uint4(i1.x, i1.y, i1.z, i1.w), d);
+                    float sd = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sd += d[r];
+                    db1[i] += sd;
+                    uint4 zt[2];
+                    pack_tile(d, zt);
+                    stg16(a.z1f + (((size_t)tile * NT + ft) * 2 + 0) * 64, lo16, zt[0]);
+                    stg16(a.z1f + (((size_t)tile * NT + ft) * 2 + 1) * 64, lo16, zt[1]);
+                }
             }
             BSTAMP(5);
             BSTAMP(6);
