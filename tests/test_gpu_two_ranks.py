@@ -233,3 +233,20 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(P):
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
     assert out["allreduce"] == "torch.distributed/gloo"
     assert out["strong"]["envs_per_gpu"] == 32 and out["strong"]["value"] > 0
+
+
+def test_bench_stream_flag(P, tmp_path):
+    """bench.py --stream DIR: the timed loop collects through a fresh DiskRollouts per iteration (BASELINE config 5 wording);
+    the line says so, is flagged non-headline, and the last iteration's rollout.bin is on disk with the compact record."""
+    from test_host_logic import _run_bench
+    d = str(tmp_path / "stream")
+    r, out = _run_bench({}, "--steps", "2", "--warmup", "1", "--envs", "96", "--t-steps", "8", "--epochs", "1",
+                        "--no-cpu-baseline", "--stream", d, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out["config"]["rollouts_streamed_to_disk"] is True and out["headline_config"] is False and out["value"] > 0
+    f = os.path.join(d, "rank0", "rollout.bin")
+    assert os.path.isfile(f)
+    hdr = open(f, "rb").read(40)
+    assert hdr[:4] == b"PPOR" and int.from_bytes(hdr[4:8], "little") == 2          # version 2: env snapshots
+    assert int.from_bytes(hdr[8:16], "little") == 96                                 # N
+    assert os.path.getsize(f) == 40 + 8 * 96 * (64 + 17) + 8 * 96 * 4               # header + T records + returns column
