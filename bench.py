@@ -43,6 +43,10 @@ def flops_per_state(kind):
     if kind == "fwd":
         return fwd
     # backward: dH1 = W2^T dZ2 (HID*HID), dW2 (HID*HID), dW1 (HID*F), dW3/dH2 (2*HID*4)
+    if kind == "bwd_no_dw1":             # bf16 mode at HID = 256: dW1 = dZ1 X^T runs in k_policy_dw1_bf16, not in k_policy_bwd_bf16
+        return 2 * rows * (2 * HID * HID + 2 * HID * 4)
+    if kind == "dw1":
+        return 2 * rows * HID * F
     return 2 * rows * (2 * HID * HID + HID * F + 2 * HID * 4)
 
 
@@ -141,6 +145,24 @@ def cpu_baseline_blas(threads=None):
     return {"value": M / dt, "unit": "env-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": "same path with the MLP on host BLAS/autograd (torch CPU fp32): %d envs x %d steps, %d epochs, "
                       "minibatch %d, %.1f s on %d threads" % (n_env, T, EPOCHS, B, dt, torch.get_num_threads())}
+
+
+def cpu_baseline_julia():
+    """the REFERENCE's own Julia path (its collect_rollouts! + ppo_train!, included unmodified from a
+    checkout) against a Julia implementation of the same synthetic env and MLP: bench/julia_reference.jl.  Runs only when
+    `julia` is on PATH and PPO_JULIA_REFERENCE names a ProximalPolicyOptimization.jl checkout (with Flux, Distributions,
+    BSON, CSV, DataFrames, Tables loadable); returns None otherwise -- the expected case on the build image and the GPU
+    box (no julia, no network) -- and the line then carries no `cpu_baseline_julia` key."""
+    import shutil
+    jl, ref = shutil.which("julia"), os.environ.get("PPO_JULIA_REFERENCE", "")
+    if not jl or not os.path.isdir(os.path.join(ref, "src")):
+        return None
+    r = subprocess.run([jl, "--threads=1", os.path.join(ROOT, "bench", "julia_reference.jl"), ref, "64", str(T_STEPS), str(EPOCHS), "4096"],
+                       capture_output=True, text=True, timeout=float(os.environ.get("PPO_JULIA_TIMEOUT", "1500")))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"value": None, "error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(lines[-1])
 
 
 def cpu_baseline_all_cores():
@@ -360,7 +382,12 @@ def main():
         # k_rollout_persistent: the whole rollout (T steps of every env: observe + MLP + sample + step!) in one launch
         # (the default for Q = 8 in fp32 mode); k_policy_fwd_rollout is the per-step form (bf16 mode, Q = 32, disk
         # streaming, PPO_ROLLOUT_PERSISTENT=0)
-        for name, kind, per in [("k_policy_bwd", "bwd", MINIBATCH), ("k_policy_fwd_train", "fwd", MINIBATCH),
+        # bf16 mode at HID = 256 runs the backward as a PAIR of launches (k_policy_bwd_bf16 + k_policy_dw1_bf16): the
+        # per-kernel rows carry each kernel's own flops, the roofline line carries the pair (sum of times, full flops)
+        dw1_ms, dw1_n = PPO.profile_get("k_policy_dw1")
+        split_dw1 = dw1_n > 0
+        for name, kind, per in [("k_policy_bwd", "bwd_no_dw1" if split_dw1 else "bwd", MINIBATCH), ("k_policy_dw1", "dw1", MINIBATCH),
+                                ("k_policy_fwd_train", "fwd", MINIBATCH),
                                 ("k_policy_fwd_rollout", "fwd", N_ENVS), ("k_rollout_persistent", "fwd", N_ENVS * T_STEPS)]:
             ms, n = PPO.profile_get(name)
             if n:
@@ -370,7 +397,12 @@ def main():
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
                                  "frac": round(tf / peak, 4)}
-        for name in ("k_policy_bwd_data", "k_policy_wgrad", "k_policy_dw1", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
+        if split_dw1 and "k_policy_bwd" in kernels:
+            pair_ms = kernels["k_policy_bwd"]["avg_ms"] + kernels["k_policy_dw1"]["avg_ms"]
+            tf = flops_per_state("bwd") * MINIBATCH / (pair_ms * 1e-3) / 1e12
+            kernels["k_policy_bwd+k_policy_dw1"] = {"avg_ms": round(pair_ms, 4), "launches": kernels["k_policy_bwd"]["launches"],
+                                                    "tflops": round(tf, 2), "frac": round(tf / peak, 4)}
+        for name in ("k_policy_bwd_data", "k_policy_wgrad", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
                      "k_reduce_adam", "allreduce"):
             ms, n = PPO.profile_get(name)
             if n:
@@ -392,7 +424,7 @@ def main():
             gbs = 17.0 * 128 * cols / (ms * 1e-3) / 1e9
             kernels["k_gae_tn@%dx128" % cols] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
                                                   "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
-        k = kernels.get("k_policy_bwd")
+        k = kernels.get("k_policy_bwd+k_policy_dw1") or kernels.get("k_policy_bwd")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
             # inside this process); null when no pass was made for this exact launch shape
@@ -407,7 +439,8 @@ def main():
             except Exception:
                 pass
             tiles = MINIBATCH * (QUADS // 8)
-            roof = {"bound": "mfma", "kernel": "k_policy_bwd", "achieved": k["tflops"], "peak": peak,
+            roof = {"bound": "mfma", "kernel": "k_policy_bwd+k_policy_dw1 (the backward is two launches in this mode)" if split_dw1 else "k_policy_bwd",
+                    "achieved": k["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
                     # context for `frac` (profiles/history/r01_mfma_f32_valu_overlap.txt): on gfx950 the fp32 MFMA
@@ -468,9 +501,11 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             for key, fn in (("cpu_baseline", cpu_baseline), ("cpu_baseline_blas", cpu_baseline_blas),
                             ("cpu_baseline_blas_1core", lambda: cpu_baseline_blas(threads=1)),
-                            ("cpu_baseline_all_cores", cpu_baseline_all_cores)):
+                            ("cpu_baseline_all_cores", cpu_baseline_all_cores), ("cpu_baseline_julia", cpu_baseline_julia)):
                 try:
-                    out[key] = fn()
+                    res = fn()
+                    if res is not None:     # cpu_baseline_julia: absent unless julia + a reference checkout are present
+                        out[key] = res
                 except Exception as e:      # the oracle is only a reported baseline
                     out[key] = {"value": None, "error": str(e)}
         else:

@@ -233,7 +233,12 @@ int32_t ppo_step_batch(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro,
                        const int64_t* sample_idx, int64_t B, double epsilon, double entropy_weight,
                        int32_t adv_mode, double* ppoloss, double* entropyloss);
 /* all-reduce hook: called once per optimiser step between backward and Adam with the device
- * gradient buffer (sum over ranks expected on return, enqueued on / ordered with the stream) */
+ * gradient buffer (sum over ranks expected on return, enqueued on / ordered with the stream).
+ * Contract: the hook must reduce EXACTLY the buffer it is handed on each call -- `grad_dev`, `n_floats` floats -- and it
+ * must SUM (not average): ppo_train also calls it on two small non-gradient buffers at its start (the shard-length
+ * exchange, 2 * world floats, and a 1-float status agreement), so a hook that ignores the pointer / count and reduces a
+ * cached gradient tensor, or one that divides by the world size, breaks the exchange (ppo_train then fails on every
+ * rank alike with "shard-length exchange is inconsistent").  Return 0 on success. */
 typedef int32_t (*ppo_allreduce_fn)(void* ctx, void* grad_dev, int64_t n_floats);
 /* ppo_train!(policy, optimizer, dataset, epsilon, batch_size, num_epochs, entropy_weight)
  *                                                          src/train.jl:86-153
@@ -285,6 +290,22 @@ int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir);
  * `scratch` is a rollout buffer created for this env (its contents are overwritten). */
 int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
                             double* mean, double* std);
+
+/* Evaluator variants (test/quad_game_utilities.jl:280-307,369-387), same trajectory-to-env assignment as
+ * ppo_average_returns.  env.current_score of the synthetic env = sum of |vertex score| over the active quads,
+ * env.opt_score = |sum of vertex scores| (the two numbers its termination test compares).
+ *   average_best_returns:       mean / sample std of  initial_score - min(score seen on the trajectory)      :280-307
+ *   average_normalized_returns: the same divided by maxreturn = initial_score - opt_score; a trajectory whose
+ *                               maxreturn is 0 counts 1.0 and is NOT played (:369-378)                        :369-387
+ * ppo_evaluate_trajectories returns the per-trajectory values themselves (kind 1 = single_trajectory_return
+ * src/evaluate.jl:1-16, 2 = best_single_trajectory_return, 3 = single_trajectory_normalized_return), env-major:
+ * env n's trajectories (e = n, n + N, ...) are consecutive. */
+int32_t ppo_average_best_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                                 double* mean, double* std);
+int32_t ppo_average_normalized_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch,
+                                       int64_t num_trajectories, double* mean, double* std);
+int32_t ppo_evaluate_trajectories(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                                  int32_t kind, double* values);
 
 /* timing of the dominant kernels of the last ppo_train / ppo_collect_rollouts call, measured with
  * HIP events on the engine's stream (bench.py roofline leg) */

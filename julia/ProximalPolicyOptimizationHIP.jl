@@ -157,6 +157,33 @@ function PPO.average_returns(p::HipPolicy, env::HipVecEnv, num_trajectories)
     m[], s[]
 end
 
+# evaluator variants of test/quad_game_utilities.jl:280-307,369-387 (argument order as there: env first)
+function average_best_returns(env::HipVecEnv, p::HipPolicy, num_trajectories)
+    scratch = HipRollouts()
+    h = ensure!(scratch, env, 1)
+    m, s = Ref{Float64}(), Ref{Float64}()
+    check(ccall((:ppo_average_best_returns, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Float64}),
+                p.h, env.h, h, num_trajectories, m, s))
+    m[], s[]
+end
+function average_normalized_returns(env::HipVecEnv, p::HipPolicy, num_trajectories)
+    scratch = HipRollouts()
+    h = ensure!(scratch, env, 1)
+    m, s = Ref{Float64}(), Ref{Float64}()
+    check(ccall((:ppo_average_normalized_returns, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Float64}, Ref{Float64}),
+                p.h, env.h, h, num_trajectories, m, s))
+    m[], s[]
+end
+# per-trajectory values: kind 1 = single_trajectory_return, 2 = best_single_trajectory_return, 3 = single_trajectory_normalized_return
+function evaluate_trajectories(env::HipVecEnv, p::HipPolicy, num_trajectories, kind)
+    scratch = HipRollouts()
+    h = ensure!(scratch, env, 1)
+    v = zeros(Float64, num_trajectories)
+    check(ccall((:ppo_evaluate_trajectories, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Float64}),
+                p.h, env.h, h, num_trajectories, Int32(kind), v))
+    v
+end
+
 # batch_advantage plugin mode handed to the engine: 0 = returns (PPO.batch_advantage above), 1 = normalised returns,
 # 2 / 3 = GAE(gamma, lambda) / normalised GAE over values supplied through compute_gae!
 const ADV_MODE = Ref{Int32}(0)

@@ -48,7 +48,8 @@ __all__ = [
     "compute_returns_tn", "gae_tn", "compute_gae_", "profile_gae", "collect_rollouts_", "collect_rollouts_steps_", "construct_dataset",
     "simplified_ppo_clip", "get_linear_action_index", "ppo_loss_with_entropy", "categorical_sample", "step_batch_",
     "ppo_train_", "ppo_iterate_", "get_optimizer_learning_rate", "index_to_action", "action_mask", "DataParallel",
-    "device_count", "average_returns", "DiskRollouts", "DiskDataset", "update_", "write_returns_to_disk",
+    "device_count", "average_returns", "average_best_returns", "average_normalized_returns",
+    "evaluate_trajectories", "DiskRollouts", "DiskDataset", "update_", "write_returns_to_disk",
     "export_reference_layout", "load_disk_rollouts", "bson_encode_state", "bson_decode_state", "philox4x32_10", "profile_enable", "profile_get", "synchronize",
     "HostRollouts", "HostDataset", "update_rollouts_", "compute_state_value_", "collect_step_data_", "collect_episode_data_",
     "permute_", "shuffle_", "single_trajectory_return", "smoothed_entropy", "clamped_entropy", "ppo_loss", "step_epoch_",
@@ -879,6 +880,40 @@ def average_returns(policy, env, num_trajectories):
     m, s = C.c_double(0), C.c_double(0)
     call("ppo_average_returns", policy._h, env._h, h, int(num_trajectories), C.byref(m), C.byref(s))
     return m.value, s.value
+
+
+def _evaluator_scratch(env):
+    scratch = BufferRollouts()
+    return scratch, scratch._ensure(env, 1)
+
+
+def average_best_returns(env, policy, num_trajectories):
+    """average_best_returns(wrapper, policy, num_trajectories) (test/quad_game_utilities.jl:299-307; note the
+    reference's argument order: env first) -> (mean, std) of initial_score - lowest score seen on the trajectory."""
+    scratch, h = _evaluator_scratch(env)
+    m, s = C.c_double(0), C.c_double(0)
+    call("ppo_average_best_returns", policy._h, env._h, h, int(num_trajectories), C.byref(m), C.byref(s))
+    return m.value, s.value
+
+
+def average_normalized_returns(env, policy, num_trajectories):
+    """average_normalized_returns(wrapper, policy, num_trajectories) (test/quad_game_utilities.jl:380-387) ->
+    (mean, std) of best return / (initial_score - opt_score); a trajectory that starts at its optimum counts 1.0."""
+    scratch, h = _evaluator_scratch(env)
+    m, s = C.c_double(0), C.c_double(0)
+    call("ppo_average_normalized_returns", policy._h, env._h, h, int(num_trajectories), C.byref(m), C.byref(s))
+    return m.value, s.value
+
+
+def evaluate_trajectories(env, policy, num_trajectories, kind):
+    """Per-trajectory values behind the three evaluators: kind "return" (single_trajectory_return, src/evaluate.jl:1-16),
+    "best" (best_single_trajectory_return, test/quad_game_utilities.jl:280-296) or "normalized"
+    (single_trajectory_normalized_return, :369-378).  Env-major order: env n's trajectories are consecutive."""
+    k = {"return": 1, "best": 2, "normalized": 3}[kind]
+    scratch, h = _evaluator_scratch(env)
+    out = np.zeros(int(num_trajectories), np.float64)
+    call("ppo_evaluate_trajectories", policy._h, env._h, h, int(num_trajectories), k, _p(out, _lib.c_f64p))
+    return out
 
 
 # ------------------------------------------------------------------ data parallel (one process per GPU)

@@ -96,6 +96,9 @@ SIGNATURES = {
     "ppo_rollouts_detach_disk": [H],
     "ppo_rollouts_load_disk": [H, C.c_char_p],
     "ppo_average_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
+    "ppo_average_best_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
+    "ppo_average_normalized_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
+    "ppo_evaluate_trajectories": [H, H, H, C.c_int64, C.c_int32, c_f64p],
     "ppo_profile_returns": [C.c_int64, C.c_int64, C.c_double, C.c_int32, c_f64p],
     "ppo_profile_gae": [C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32, c_f64p],
     "ppo_rollouts_compute_gae": [H, c_f32p, C.c_double, C.c_double, c_f32p, c_f32p],

@@ -605,6 +605,12 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
         for (int64_t t0 = 0; t0 < T; t0 += chunk) {
             const int64_t tc = std::min(chunk, T - t0);
             ps = launch_policy_rollout_persistent(pol, env, ro, tc, record_probs, t0);
+            if (ps == PPO_ERR_UNSUPPORTED && t0 > 0) {
+                // the per-step fallback restarts at t = 0, but the envs have advanced t0 steps and their records are
+                // already enqueued to the sink: a shape that stops being covered mid-chain is a hard error
+                ppo_set_error("collect_rollouts!: the one-launch rollout became unavailable in the middle of a streamed collection");
+                return PPO_ERR_UNSUPPORTED;
+            }
             if (ps != PPO_OK) break;                                       // t0 == 0: shape not covered -> per-step launches
             for (int64_t t = t0; t < t0 + tc; ++t) PPO_TRY(disk_sink_step(ro, t));
         }
@@ -716,6 +722,88 @@ int32_t ppo_average_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scra
     for (double x : rets) v += (x - m) * (x - m);
     *mean = m;
     *std = rets.size() > 1 ? std::sqrt(v / (double)(rets.size() - 1)) : NAN;   // Flux.std: corrected (n-1)
+    return PPO_OK;
+}
+
+// Evaluator variants on the device (test/quad_game_utilities.jl:280-307,369-387; kind 1 = src/evaluate.jl:1-16): exactly
+// num_trajectories whole episodes, trajectory e on resident env e mod N like ppo_collect_rollouts_episodes; the
+// per-episode value is tracked inside the env step (k_env_step, EvalView), nothing but one value per trajectory
+// comes back.  Row 0 of `scratch` is the only rollout storage touched.  values: [num_trajectories], env-major.
+static int32_t evaluate_impl(ppo_policy_s* pol, ppo_env_s* env, ppo_rollouts_s* scratch, int64_t num_traj, int32_t kind,
+                             std::vector<double>& values) {
+    PPO_TRY(check_shapes(scratch, env, pol));
+    ARG_CHECK(num_traj >= 1, "evaluator: num_trajectories must be >= 1");
+    ARG_CHECK(kind >= 1 && kind <= 3, "evaluator: kind must be 1 (return), 2 (best return) or 3 (normalised best return)");
+    const int64_t N = env->N;
+    const int64_t per_env = (num_traj + N - 1) / N;
+    const int64_t Tmax = per_env * ((int64_t)env->max_actions + 1);      // + 1: a skipped (maxreturn == 0) episode costs one step
+    PPO_TRY(rollouts_reserve(scratch, 1, false));
+    DevBuf<double> ep_ret, out; DevBuf<int32_t> ep_i;
+    PPO_TRY(ep_ret.alloc((size_t)N)); PPO_TRY(out.alloc((size_t)num_traj)); PPO_TRY(ep_i.alloc((size_t)4 * N));
+    HIP_TRY(hipMemsetAsync(ep_ret.p, 0, (size_t)N * 8, g_stream));
+    HIP_TRY(hipMemsetAsync(ep_i.p, 0, (size_t)4 * N * 4, g_stream));
+    HIP_TRY(hipMemsetAsync(out.p, 0, (size_t)num_traj * 8, g_stream));
+    EvalView ev;
+    ev.kind = kind; ev.ep_ret = ep_ret.p; ev.ep_init = ep_i.p; ev.ep_min = ep_i.p + N; ev.ep_maxret = ep_i.p + 2 * N;
+    ev.ep_count = ep_i.p + 3 * N; ev.out = out.p; ev.num_traj = num_traj;
+    hipLaunchKernelGGL(k_episode_quota, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, g_stream, env->episodes_left.p, N,
+                       num_traj);
+    PPO_TRY(launch_env_reset(env, 0));                                  // reset!(env) before the first trajectory
+    std::vector<int32_t> left((size_t)N);
+    bool all = false;
+    for (int64_t t = 0; t < Tmax && !all; ++t) {
+        PPO_TRY(launch_env_observe(env, scratch->states.p, scratch->active.p));
+        PPO_TRY(launch_policy_rollout(pol, env, scratch->states.p, scratch->active.p, scratch->actions.p, scratch->p_sel.p, nullptr));
+        PPO_TRY(launch_env_step(env, scratch->actions.p, scratch->rewards.p, scratch->done.p, scratch->valid.p, 0, 1, &ev));
+        if ((t & 7) == 7 || t + 1 == Tmax) {            // poll completion every 8 steps
+            PPO_TRY(d2h(left.data(), env->episodes_left.p, (size_t)N));
+            all = true;
+            for (int64_t n = 0; n < N; ++n) if (left[n] > 0) { all = false; break; }
+        }
+    }
+    ARG_CHECK(all, "evaluator: the episodes did not finish within max_actions steps each");
+    scratch->T = 0; scratch->len = 0; scratch->adv_T = -1;
+    values.resize((size_t)num_traj);
+    PPO_TRY(d2h(values.data(), out.p, (size_t)num_traj));
+    return ppo_env_check_errors(env, nullptr);
+}
+
+static void mean_std(const std::vector<double>& x, double* mean, double* std) {
+    double m = 0.0;
+    for (double v : x) m += v;
+    m /= (double)x.size();
+    double s = 0.0;
+    for (double v : x) s += (v - m) * (v - m);
+    *mean = m;
+    *std = x.size() > 1 ? std::sqrt(s / (double)(x.size() - 1)) : NAN;   // Flux.std: corrected (n-1)
+}
+
+int32_t ppo_evaluate_trajectories(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                                  int32_t kind, double* values) {
+    ARG_CHECK(pol && env && scratch && values, "evaluator: null argument");
+    std::vector<double> v;
+    PPO_TRY(evaluate_impl(pol, env, scratch, num_trajectories, kind, v));
+    std::memcpy(values, v.data(), v.size() * sizeof(double));
+    return PPO_OK;
+}
+
+// average_best_returns(wrapper, policy, num_trajectories)         test/quad_game_utilities.jl:299-307
+int32_t ppo_average_best_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                                 double* mean, double* std) {
+    ARG_CHECK(pol && env && scratch && mean && std, "average_best_returns: null argument");
+    std::vector<double> v;
+    PPO_TRY(evaluate_impl(pol, env, scratch, num_trajectories, 2, v));
+    mean_std(v, mean, std);
+    return PPO_OK;
+}
+
+// average_normalized_returns(wrapper, policy, num_trajectories)   test/quad_game_utilities.jl:380-387
+int32_t ppo_average_normalized_returns(ppo_policy_t pol, ppo_env_t env, ppo_rollouts_t scratch, int64_t num_trajectories,
+                                       double* mean, double* std) {
+    ARG_CHECK(pol && env && scratch && mean && std, "average_normalized_returns: null argument");
+    std::vector<double> v;
+    PPO_TRY(evaluate_impl(pol, env, scratch, num_trajectories, 3, v));
+    mean_std(v, mean, std);
     return PPO_OK;
 }
 
@@ -923,9 +1011,24 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
         hx[2 * (size_t)rank] = (float)(len >> 12); hx[2 * (size_t)rank + 1] = (float)(len & 4095);
         PPO_TRY(h2d(xch.p, hx.data(), hx.size()));
         if (allreduce(allreduce_ctx, xch.p, 2 * (int64_t)world) != 0) { ppo_set_error("all-reduce hook failed (shard-length exchange)"); return PPO_ERR_ARG; }
-        PPO_TRY(d2h(hx.data(), xch.p, hx.size()));
-        for (int32_t r = 0; r < world; ++r) lens[(size_t)r] = ((int64_t)hx[2 * (size_t)r] << 12) + (int64_t)hx[2 * (size_t)r + 1];
-        ARG_CHECK(lens[(size_t)rank] == len, "ppo_train!: shard-length exchange is inconsistent (two ranks with the same rank id?)");
+        // a rank that fails locally from here on must not leave the others blocked in their next collective: every rank
+        // carries its status into ONE more tiny all-reduce and all of them return together
+        int32_t local = d2h(hx.data(), xch.p, hx.size());
+        if (local == PPO_OK) {
+            for (int32_t r = 0; r < world; ++r) lens[(size_t)r] = ((int64_t)hx[2 * (size_t)r] << 12) + (int64_t)hx[2 * (size_t)r + 1];
+            if (lens[(size_t)rank] != len) {
+                ppo_set_error("AssertionError: ppo_train!: shard-length exchange is inconsistent (two ranks with the same rank id, "
+                              "or a hook that does not SUM the buffer it is handed?)");
+                local = PPO_ERR_ARG;
+            }
+        }
+        float bad = local == PPO_OK ? 0.0f : 1.0f;
+        const int32_t hs = h2d(xch.p, &bad, 1);
+        if (allreduce(allreduce_ctx, xch.p, 1) != 0) { ppo_set_error("all-reduce hook failed (status agreement)"); return PPO_ERR_ARG; }
+        PPO_TRY(hs);
+        PPO_TRY(d2h(&bad, xch.p, 1));
+        if (local != PPO_OK) return local;
+        if (bad != 0.0f) { ppo_set_error("ppo_train!: another data-parallel rank failed in the shard-length exchange"); return PPO_ERR_ARG; }
     }
     int64_t nb = 0, min_len = len;
     for (int64_t l : lens) { nb = std::max(nb, (l + batch_size - 1) / batch_size); min_len = std::min(min_len, l); }

@@ -4,6 +4,7 @@
 // thread drains the pinned ring into one append-only file.
 //
 // File format (little endian): header {magic "PPOR", u32 version, i64 N, i32 H, i32 F, i32 A, i32 V, i64 T}
+// (version 2: then {u64 FNV-1a of the template-vertex table, i32 env kind, i32 0}, checked on load)
 // then T step records  [states][active N u32][actions N i32][p_sel N f32][rewards N f32][done N u8]
 // then the returns column [T][N] f32 (written after compute_returns).
 //   version 1: states = the expanded observations, N*H*F int8 (2304 B per env-step for Q = 8)
@@ -21,8 +22,22 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <cstdlib>
+#include <cerrno>
 
 struct DiskHeader { char magic[4]; uint32_t version; int64_t N; int32_t H, F, A, V; int64_t T; };
+// version 2 only, directly behind the header: FNV-1a of the [H][36] template-vertex table the snapshots are expanded with.
+// A snapshot file stores vertex scores / degrees, not observations: loading it into a buffer created for another env
+// kind (another table) would silently re-derive different rows.
+struct DiskTemplateTag { uint64_t tmpl_hash; int32_t env_kind; int32_t reserved; };
+static int32_t template_hash(const ppo_rollouts_s* ro, uint64_t* out) {
+    std::vector<int8_t> t((size_t)ro->H * PPO_TPL);
+    HIP_TRY(hipMemcpyAsync(t.data(), ro->tmpl.p, t.size(), hipMemcpyDeviceToHost, ppo_stream()));
+    HIP_TRY(hipStreamSynchronize(ppo_stream()));
+    uint64_t h = 1469598103934665603ull;
+    for (int8_t b : t) { h ^= (uint8_t)b; h *= 1099511628211ull; }
+    *out = h;
+    return PPO_OK;
+}
 
 struct DiskSink {
     std::string dir;
@@ -85,7 +100,8 @@ static int rm_rf(const std::string& path) {
 static bool write_all(int fd, struct iovec* iov, int n) {
     while (n > 0) {
         ssize_t w = writev(fd, iov, n);
-        if (w < 0) return false;
+        if (w < 0 && errno == EINTR) continue;          // interrupted before anything was written: retry
+        if (w <= 0) return false;                       // error, or a device that accepts nothing (would spin forever)
         while (n > 0 && (size_t)w >= iov->iov_len) { w -= (ssize_t)iov->iov_len; ++iov; --n; }
         if (n > 0 && w > 0) { iov->iov_base = (char*)iov->iov_base + w; iov->iov_len -= (size_t)w; }
     }
@@ -126,6 +142,9 @@ void disk_sink_destroy(DiskSink* s) {
         s->writer.join();
     }
     if (s->f) fclose(s->f);
+    // a device -> host copy may still be in flight into a record (error / early-detach paths): the records go back to a
+    // process-wide pool, so nobody else may receive one before the copy stream has drained
+    if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     for (char* p : s->pinned) pinned_put(s->rec_bytes, p);
     for (auto e : s->produced) (void)hipEventDestroy(e);
     for (auto e : s->copied) (void)hipEventDestroy(e);
@@ -187,22 +206,38 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     if (s->f) { fclose(s->f); s->f = nullptr; }
     s->enq = s->written = 0; s->stop = false; s->failed = false;
     const size_t rec = record_bytes(ro, ro->compact);           // the storage form is decided per collection
+    if (s->copy_stream) HIP_TRY(hipStreamSynchronize(s->copy_stream));   // nothing of a previous collection is still landing
     if (rec != s->rec_bytes) {
         for (char*& p : s->pinned) { pinned_put(s->rec_bytes, p); p = nullptr; }
         s->rec_bytes = rec;
         for (int i = 0; i < s->slots; ++i)
-            if (!(s->pinned[i] = pinned_get(rec))) { ppo_set_error("DiskRollouts: pinned allocation failed"); return PPO_ERR_HIP; }
+            if (!(s->pinned[i] = pinned_get(rec))) {
+                // hand back what was obtained and forget the size, so the next begin allocates again instead of
+                // finding rec == rec_bytes with null slots
+                for (char*& p : s->pinned) { pinned_put(rec, p); p = nullptr; }
+                s->rec_bytes = 0;
+                ppo_set_error("DiskRollouts: pinned allocation failed");
+                return PPO_ERR_HIP;
+            }
     }
     const std::string path = s->dir + "/rollout.bin";
     s->f = fopen(path.c_str(), "wb");
     if (!s->f) { ppo_set_error("DiskRollouts: cannot open " + path); return PPO_ERR_ARG; }
     DiskHeader h;
     memcpy(h.magic, "PPOR", 4); h.version = ro->compact ? 2 : 1; h.N = ro->N; h.H = ro->H; h.F = ro->F; h.A = ro->A; h.V = ro->V; h.T = T;
-    if (fwrite(&h, sizeof(h), 1, s->f) != 1 || fflush(s->f) != 0) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
+    bool hdr_ok = fwrite(&h, sizeof(h), 1, s->f) == 1;
+    size_t hdr_bytes = sizeof(h);
+    if (ro->compact) {
+        DiskTemplateTag tag = {0, 0, 0};
+        PPO_TRY(template_hash(ro, &tag.tmpl_hash));
+        hdr_ok = hdr_ok && fwrite(&tag, sizeof(tag), 1, s->f) == 1;
+        hdr_bytes += sizeof(tag);
+    }
+    if (!hdr_ok || fflush(s->f) != 0) { ppo_set_error("DiskRollouts: header write failed"); return PPO_ERR_ARG; }
     // records go out through the descriptor (writev), the returns column and the close through the FILE again: the stream is
     // flushed here and holds nothing in between.  Blocks reserved up front where the file system can (no per-call
     // allocation; KEEP_SIZE: the file still grows by appending, a short collection leaves no zero tail)
-    (void)fallocate(fileno(s->f), FALLOC_FL_KEEP_SIZE, 0, (off_t)(sizeof(h) + (size_t)T * rec + (size_t)T * ro->N * 4));
+    (void)fallocate(fileno(s->f), FALLOC_FL_KEEP_SIZE, 0, (off_t)(hdr_bytes + (size_t)T * rec + (size_t)T * ro->N * 4));
     s->batch = std::max(1, s->slots / 2);
     if (const char* e = getenv("PPO_DISK_BATCH")) s->batch = std::max(1, std::min(s->slots, atoi(e)));
     s->writer = std::thread(writer_loop, s);
@@ -266,6 +301,18 @@ extern "C" int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir) {
     }
     const bool compact = h.version == 2;
     if (h.N != ro->N || h.H != ro->H || h.F != ro->F || (compact && h.V != ro->V)) { fclose(f); ppo_set_error("DiskDataset: shape mismatch"); return PPO_ERR_ARG; }
+    if (compact) {
+        DiskTemplateTag tag;
+        uint64_t mine = 0;
+        if (fread(&tag, sizeof(tag), 1, f) != 1) { fclose(f); ppo_set_error("DiskDataset: bad header"); return PPO_ERR_ARG; }
+        const int32_t hs = template_hash(ro, &mine);
+        if (hs != PPO_OK) { fclose(f); return hs; }
+        if (tag.tmpl_hash != mine) {
+            fclose(f);
+            ppo_set_error("DiskDataset: the env snapshots were written for another env (template table differs from this buffer's)");
+            return PPO_ERR_ARG;
+        }
+    }
     const int64_t T = h.T;
     const size_t N = (size_t)ro->N, sb = state_bytes(ro, compact), rec = record_bytes(ro, compact);
     std::vector<char> buf(rec);
@@ -291,18 +338,24 @@ extern "C" int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir) {
         PPO_TRY(ppo_rollouts_set(ro, T, st.data(), act.data(), a0.data(), ps.data(), ret.data(), dn.data()));
     } else {                                      // env snapshots go back as they are: the buffer stays in the compact form
         PPO_TRY(rollouts_reserve(ro, T, true));
+        ro->T = T; ro->adv_T = -1;
+        PPO_TRY(set_index_all(ro));                  // before the copies below: no early return while they are in flight
         const size_t n = (size_t)T * N;
         hipStream_t s = ppo_stream();
-        HIP_TRY(hipMemcpyAsync(ro->cstate.p, st.data(), st.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ro->active.p, act.data(), n * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ro->actions.p, a0.data(), n * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ro->p_sel.p, ps.data(), n * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ro->returns.p, ret.data(), n * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ro->done.p, dn.data(), n, hipMemcpyHostToDevice, s));
-        ro->T = T; ro->adv_T = -1;
-        PPO_TRY(set_index_all(ro));
+        // the sources are local vectors: whatever happens, the stream is drained before this function returns
+        hipError_t e = hipMemcpyAsync(ro->cstate.p, st.data(), st.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ro->active.p, act.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ro->actions.p, a0.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ro->p_sel.p, ps.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ro->returns.p, ret.data(), n * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ro->done.p, dn.data(), n, hipMemcpyHostToDevice, s);
+        const hipError_t es = hipStreamSynchronize(s);
+        HIP_TRY(e);
+        HIP_TRY(es);
     }
-    HIP_TRY(hipMemcpyAsync(ro->rewards.p, rw.data(), (size_t)T * N * 4, hipMemcpyHostToDevice, ppo_stream()));
-    HIP_TRY(hipStreamSynchronize(ppo_stream()));
+    const hipError_t e2 = hipMemcpyAsync(ro->rewards.p, rw.data(), (size_t)T * N * 4, hipMemcpyHostToDevice, ppo_stream());
+    const hipError_t es2 = hipStreamSynchronize(ppo_stream());
+    HIP_TRY(e2);
+    HIP_TRY(es2);
     return PPO_OK;
 }

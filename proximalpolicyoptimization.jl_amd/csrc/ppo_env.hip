@@ -45,9 +45,13 @@ __global__ void k_env_reset(EnvView e, int only_done) {
 
 // step!(env, a) for every env + record reward/is_terminal + optional auto-reset
 // (call order src/collect_rollouts.jl:9-12; reset before the next episode src/rollout_buffer.jl:75).
+// ev.kind != 0 (episodes mode only): the evaluator variants' per-episode values are tracked here, one thread per env --
+// best_single_trajectory_return / single_trajectory_normalized_return (test/quad_game_utilities.jl:280-296,369-378) and
+// single_trajectory_return (src/evaluate.jl:1-16).  env.current_score = sum |vertex score| over the active quads,
+// env.opt_score = |sum of vertex scores| (the synthetic env's termination test uses the same two numbers).
 __global__ void k_env_step(EnvView e, const int32_t* __restrict__ actions, float* __restrict__ reward_out,
                            uint8_t* __restrict__ done_out, uint8_t* __restrict__ valid_out, int auto_reset,
-                           int episodes_mode) {
+                           int episodes_mode, EvalView ev) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= e.N) return;
     if (episodes_mode && e.episodes_left[n] <= 0) {          // this env already played its episodes
@@ -56,13 +60,49 @@ __global__ void k_env_step(EnvView e, const int32_t* __restrict__ actions, float
         if (done_out) done_out[n] = 1;
         return;
     }
+    const EnvRef er = ref_of(e, n);
+    int64_t slot = 0;
+    if (ev.kind) {
+        const int64_t q = ev.num_traj / e.N, rem = ev.num_traj % e.N;
+        slot = n * q + (n < rem ? n : rem) + ev.ep_count[n];          // env n's episodes are consecutive in `out`
+        if (*er.steps == 0) {                                        // first step! of an episode: the values at reset!
+            const uint32_t act = *er.active;
+            const int cur = env_total_abs(er.sc, act, e.Q), sum = env_total_sum(er.sc, act, e.Q);
+            const int mr = cur - (sum < 0 ? -sum : sum);
+            if (ev.kind == 3 && mr == 0) {
+                // single_trajectory_normalized_return: maxreturn == 0 -> 1.0 and the episode is not played (:372-373).
+                // The action sampled for this state is dropped; the next step sees the env's next episode.
+                ev.out[slot] = 1.0;
+                ev.ep_count[n] += 1;
+                const int left = e.episodes_left[n] - 1;
+                e.episodes_left[n] = left;
+                if (left > 0) env_reset_one(e, n);
+                if (valid_out) valid_out[n] = 0;
+                if (reward_out) reward_out[n] = 0.0f;
+                if (done_out) done_out[n] = 1;
+                return;
+            }
+            ev.ep_ret[n] = 0.0; ev.ep_init[n] = cur; ev.ep_min[n] = cur; ev.ep_maxret[n] = mr;
+        }
+    }
     float rew; uint8_t dn;
-    const int errf = env_step_ref(const_of(e), ref_of(e, n), actions[n], rew, dn);
+    int score_after = 0;
+    const int errf = env_step_ref(const_of(e), er, actions[n], rew, dn, &score_after);
     if (errf) atomicOr(e.err, errf);
     if (errf & 4) return;                          // step! on a terminated env: nothing recorded (as before)
     if (reward_out) reward_out[n] = rew;
     if (done_out) done_out[n] = dn;
     if (valid_out) valid_out[n] = 1;
+    if (ev.kind) {
+        const double ret = ev.ep_ret[n] + (double)rew;               // ret += reward(env)   src/evaluate.jl:13
+        const int mn = min(ev.ep_min[n], score_after);               // minscore = min(minscore, env.current_score)
+        ev.ep_ret[n] = ret; ev.ep_min[n] = mn;
+        if (dn) {
+            const int best = ev.ep_init[n] - mn;                     // initial_score - minscore
+            ev.out[slot] = ev.kind == 1 ? ret : (ev.kind == 2 ? (double)best : (double)best / (double)ev.ep_maxret[n]);
+            ev.ep_count[n] += 1;
+        }
+    }
     if (dn) {
         if (episodes_mode) {
             const int left = e.episodes_left[n] - 1;
@@ -167,11 +207,11 @@ int32_t launch_env_reset(ppo_env_s* e, int only_done) {
 }
 
 int32_t launch_env_step(ppo_env_s* e, const int32_t* actions_dev, float* reward_out, uint8_t* done_out,
-                        uint8_t* valid_out, int auto_reset, int episodes_mode) {
+                        uint8_t* valid_out, int auto_reset, int episodes_mode, const EvalView* ev) {
     ProfScope ps("k_env_step");
     dim3 grid((unsigned)((e->N + 63) / 64));
     hipLaunchKernelGGL(k_env_step, grid, dim3(64), 0, ppo_stream(), view_of(e), actions_dev, reward_out, done_out,
-                       valid_out, auto_reset, episodes_mode);
+                       valid_out, auto_reset, episodes_mode, (ev && episodes_mode) ? *ev : EvalView());
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }

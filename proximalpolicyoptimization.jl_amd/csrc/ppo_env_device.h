@@ -66,8 +66,11 @@ __device__ __forceinline__ int env_total_sum(P8 sc, uint32_t act, int Q) {
 
 // step!(env, a) + reward / is_terminal (call order src/collect_rollouts.jl:9-12).  Returns the error flags to OR into
 // the device flag word (1 inactive quad, 2 index out of range, 4 step! on a terminated env: then nothing else changed).
+// score_after (optional): the env's current score (sum of |vertex score| over the active quads) behind the step -- what
+// the evaluator variants track (env.current_score, test/quad_game_utilities.jl:280-296).
 template <typename REF>
-__device__ __forceinline__ int env_step_ref(const EnvConst& c, const REF& r, int a, float& rew_out, uint8_t& done_out) {
+__device__ __forceinline__ int env_step_ref(const EnvConst& c, const REF& r, int a, float& rew_out, uint8_t& done_out,
+                                            int* score_after = nullptr) {
     const int Q = c.Q, A = 16 * Q;
     auto sc = r.sc;
     auto dg = r.dg;
@@ -122,6 +125,7 @@ __device__ __forceinline__ int env_step_ref(const EnvConst& c, const REF& r, int
     const uint8_t dn = (uint8_t)((new_total == opt) || (st >= c.max_actions));
     *r.reward = rew; *r.done = dn;
     rew_out = rew; done_out = dn;
+    if (score_after) *score_after = new_total;
     return errf;
 }
 

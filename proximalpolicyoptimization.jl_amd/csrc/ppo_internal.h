@@ -184,8 +184,21 @@ int32_t launch_gae_tn(const float* r, const uint8_t* done, const float* values, 
                       int64_t T, int64_t N, double gamma, double lambda);
 
 int32_t launch_env_reset(ppo_env_s* e, int only_done);
+// evaluator bookkeeping folded into the env step of the episodes mode (test/quad_game_utilities.jl:280-307,369-387,
+// src/evaluate.jl:1-25): per-env running values of the episode in flight, one result per finished episode
+struct EvalView {
+    int32_t kind = 0;              // 0 off, 1 return (sum of rewards), 2 best return (initial score - lowest score seen),
+                                   // 3 normalised best return (best / (initial score - optimum score); 1.0 when that is 0)
+    double* ep_ret = nullptr;      // [N] reward sum of the episode in flight
+    int32_t* ep_init = nullptr;    // [N] score at its reset
+    int32_t* ep_min = nullptr;     // [N] lowest score seen so far
+    int32_t* ep_maxret = nullptr;  // [N] initial score - optimum score
+    int32_t* ep_count = nullptr;   // [N] episodes this env has finished
+    double* out = nullptr;         // [num_traj] results, env-major (env n's episodes are consecutive)
+    int64_t num_traj = 0;
+};
 int32_t launch_env_step(ppo_env_s* e, const int32_t* actions_dev, float* reward_out, uint8_t* done_out,
-                        uint8_t* valid_out, int auto_reset, int episodes_mode);
+                        uint8_t* valid_out, int auto_reset, int episodes_mode, const EvalView* ev = nullptr);
 int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out);
 // compact rollout storage: env snapshot of every env (score[V] then degree[V]) -> cstate_out [N][2V]
 int32_t launch_env_snapshot(ppo_env_s* e, int8_t* cstate_out);

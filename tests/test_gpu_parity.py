@@ -896,6 +896,64 @@ def test_average_returns_evaluator(P, orc):
     assert abs(mean - np.mean(rets)) < 1e-9 and abs(std - np.std(rets, ddof=1)) < 1e-9
 
 
+def _oracle_scores(oenv, n):
+    """env.current_score / env.opt_score of the synthetic env: sum |vertex score| over the active quads, |sum|."""
+    act = int(oenv.active[n])
+    sc = oenv.score[n].astype(np.int64)
+    on = np.array([(act >> (v >> 2)) & 1 for v in range(sc.size)], bool)
+    return int(np.abs(sc[on]).sum()), int(abs(sc[on].sum()))
+
+
+def _oracle_trajectories(orc, pol, N, num_traj, seed, max_actions, global_offset, kind):
+    """The reference's evaluator loops (test/quad_game_utilities.jl:280-307,369-387, src/evaluate.jl:1-25) replayed on
+    the oracle env, trajectory e on env e mod N, env-major result order."""
+    oenv = orc.Env(Q=8, max_actions=max_actions, N=N, seed=seed, global_offset=global_offset)
+    oenv.episode[:] = 1                                  # create() consumed episode 0 on the device side
+    out = []
+    for n in range(N):
+        for _ in range(len(range(n, num_traj, N))):
+            oenv.reset_one(n)                            # PPO.reset!(wrapper)
+            cur, opt = _oracle_scores(oenv, n)
+            init, minscore, maxret, ret = cur, cur, cur - opt, 0.0
+            if kind == "normalized" and maxret == 0:
+                out.append(1.0)                          # :372-373, the trajectory is not played
+                continue
+            while not oenv.done[n]:
+                p = orc.action_probabilities(pol.params, 72, 128, oenv.observe_one(n), oenv.active[n], "dev")
+                w = orc.philox([global_offset + n, int(oenv.tick[n]), 0, 0], [seed, 0])
+                a, err = orc.categorical_sample(p, orc.u01(w[0]))
+                oenv.step_one(n, a)
+                ret += float(oenv.reward[n])
+                minscore = min(minscore, _oracle_scores(oenv, n)[0])
+            best = init - minscore
+            out.append(ret if kind == "return" else (float(best) if kind == "best" else best / maxret))
+    return np.array(out, np.float64)
+
+
+@pytest.mark.parametrize("kind", ["return", "best", "normalized"])
+def test_evaluator_variants(P, orc, kind):
+    """best_single_trajectory_return / average_best_returns (test/quad_game_utilities.jl:280-307) and
+    single_trajectory_normalized_return / average_normalized_returns (:369-387) on the device, per trajectory and as
+    (mean, sample std), against the reference's loops replayed on the oracle.  Global env id 107433 with seed 13 resets
+    (episode counter 1) onto its optimum: the `maxreturn == 0 -> 1.0` branch, which does not play the trajectory."""
+    N, num_traj, seed, goff, T = 3, 8, 13, 107433, 9
+    pol = P.HipPolicy(72, 128, 2, 4, seed=5)
+    want = _oracle_trajectories(orc, pol, N, num_traj, seed, T, goff, kind)
+    env = P.HipVecEnv(num_envs=N, Q=8, max_actions=T, seed=seed, global_offset=goff)
+    got = P.evaluate_trajectories(env, pol, num_traj, kind)
+    assert np.array_equal(got, want), (got, want)
+    if kind == "normalized":
+        assert want[0] == 1.0                            # env 0's first trajectory starts at its optimum
+    env = P.HipVecEnv(num_envs=N, Q=8, max_actions=T, seed=seed, global_offset=goff)
+    if kind == "return":
+        mean, std = P.average_returns(pol, env, num_traj)
+    elif kind == "best":
+        mean, std = P.average_best_returns(env, pol, num_traj)
+    else:
+        mean, std = P.average_normalized_returns(env, pol, num_traj)
+    assert abs(mean - want.mean()) < 1e-9 and abs(std - want.std(ddof=1)) < 1e-9
+
+
 # ---------------------------------------------------------------- disk rollout store (config 5 / src/rollouts_to_disk.jl)
 def test_write_returns_to_disk_reproduces_reference_csv(P, golden_dir, tmp_path):
     """test/write_action_history.jl + output/trajectory.csv: six update! calls then write_returns_to_disk(.,1.0)
@@ -939,7 +997,7 @@ def _streamed_roundtrip(P, tmp_path, state_bytes):
             disk = P.DiskRollouts(str(tmp_path / "store"))
             P.collect_rollouts_steps_(disk, env, pol, T, 0.99, pinned_slots=2)      # 2 slots: exercises back-pressure
             assert os.path.getsize(os.path.join(disk.state_data_directory, "rollout.bin")) == \
-                40 + T * (N * state_bytes + N * 17) + T * N * 4      # header, T step records, returns column
+                40 + (16 if state_bytes == 64 else 0) + T * (N * state_bytes + N * 17) + T * N * 4   # header (+ template tag of the snapshot form), T step records, returns column
             assert len(disk) == N * T
             ro = P.load_disk_rollouts(disk.state_data_directory, env)               # DiskDataset path
         st, act = ro.state_data
@@ -966,7 +1024,7 @@ def test_streamed_disk_rollouts_full_width(P, tmp_path):
             disk = P.DiskRollouts(str(tmp_path / "wide"))
             P.collect_rollouts_steps_(disk, env, pol, T, 1.0)
             sz = os.path.getsize(os.path.join(disk.state_data_directory, "rollout.bin"))
-            assert sz == 40 + T * N * (64 + 17) + T * N * 4
+            assert sz == 40 + 16 + T * N * (64 + 17) + T * N * 4
             ro = P.load_disk_rollouts(disk.state_data_directory, env)
         else:
             P.set_rollout_compact(False)

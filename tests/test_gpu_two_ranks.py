@@ -249,4 +249,4 @@ def test_bench_stream_flag(P, tmp_path):
     hdr = open(f, "rb").read(40)
     assert hdr[:4] == b"PPOR" and int.from_bytes(hdr[4:8], "little") == 2          # version 2: env snapshots
     assert int.from_bytes(hdr[8:16], "little") == 96                                 # N
-    assert os.path.getsize(f) == 40 + 8 * 96 * (64 + 17) + 8 * 96 * 4               # header + T records + returns column
+    assert os.path.getsize(f) == 40 + 16 + 8 * 96 * (64 + 17) + 8 * 96 * 4          # header + template tag + T records + returns column

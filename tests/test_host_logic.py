@@ -2,9 +2,12 @@
 gradient all-reduce contract rehearsed with world_size-2 gloo (the oracle supplies the per-rank numbers)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_plugin_stubs_raise_like_the_reference(ppo):
@@ -155,3 +158,29 @@ def test_bench_multi_gpu_never_reports_a_single_rank_silently():
     r, out = _run_bench({"PPO_BENCH_BACKEND": "gloo"}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--envs", "64",
                         "--no-cpu-baseline")
     assert r.returncode != 0 and out is None
+
+
+def test_julia_reference_driver_is_probed_not_assumed(monkeypatch):
+    """bench/julia_reference.jl cannot run here (no julia): static checks only.  It must
+    include the reference's own module from a checkout given at run time (never a copy), drive ITS collect_rollouts! /
+    ppo_train!, and overload exactly the plugin functions the reference declares; bench.py must leave the key out when
+    `julia` or the checkout is missing."""
+    import re
+    src = open(os.path.join(ROOT, "bench", "julia_reference.jl")).read()
+    code = re.sub(r"#[^\n]*", "", src)
+    assert 'include(joinpath(REF, "src", "ProximalPolicyOptimization.jl"))' in code
+    assert "PPO.collect_rollouts!(rollouts, bank, policy" in code and "PPO.ppo_train!(policy, optimizer, dataset" in code
+    declared = {"state", "reward", "is_terminal", "reset!", "step!", "action_probabilities", "batch_action_probabilities",
+                "batch_state", "number_of_actions_per_state", "batch_advantage", "save_loss"}      # src/ProximalPolicyOptimization.jl:16-30
+    overloaded = set(re.findall(r"(?:function\s+)?PPO\.([\w!]+)\(", code)) - {"collect_rollouts!", "ppo_train!", "construct_dataset", "BufferRollouts"}
+    assert overloaded <= declared and {"state", "reward", "is_terminal", "reset!", "step!", "action_probabilities",
+                                       "batch_action_probabilities", "batch_state", "number_of_actions_per_state",
+                                       "batch_advantage"} <= overloaded, overloaded
+    assert code.count("(") == code.count(")") and code.count("[") == code.count("]")
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("PPO_JULIA_REFERENCE", "/nonexistent")
+    assert bench.cpu_baseline_julia() is None
+    monkeypatch.setenv("PATH", "/nonexistent-bin")
+    monkeypatch.setenv("PPO_JULIA_REFERENCE", ROOT)
+    assert bench.cpu_baseline_julia() is None
