@@ -79,6 +79,7 @@ def lib():
         L.orc_mlp_logits_ref.argtypes = [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f32p]
         L.orc_mlp_logits_f64.argtypes = [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f64p]
         L.orc_mlp_logits_dev.argtypes = [c_f32p, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f32p]
+        L.orc_mlp_logits_dev_n.argtypes = [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i8p, C.c_int32, c_f32p]
         L.orc_masked_softmax_ref.argtypes = [c_f32p, C.c_uint32, C.c_int32, c_f32p]
         L.orc_masked_softmax_dev.argtypes = [c_f32p, C.c_uint32, C.c_int32, c_f32p]
         L.orc_collect_rollouts_tn.argtypes = [C.POINTER(_Env), c_f32p, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
@@ -171,8 +172,7 @@ def mlp_logits(params, F, HID, x, mode="ref", n_hidden=2):
         return out
     out = np.empty(H * 4, np.float32)
     if mode == "dev":
-        assert n_hidden == 2
-        lib().orc_mlp_logits_dev(_p(p, c_f32p), F, HID, _p(x, c_i8p), H, _p(out, c_f32p))
+        lib().orc_mlp_logits_dev_n(_p(p, c_f32p), F, HID, n_hidden, _p(x, c_i8p), H, _p(out, c_f32p))
     else:
         lib().orc_mlp_logits_ref(_p(p, c_f32p), F, HID, n_hidden, _p(x, c_i8p), H, _p(out, c_f32p))
     return out

@@ -390,14 +390,15 @@ static inline int dfeat(int tile, int r, int hh) { return 32 * tile + (r & 3) + 
  * gfx950 kernels (v_mfma_f32_32x32x2_f32: D = fma(a_k1,b_k1, fma(a_k0,b_k0, C)), accumulators
  * initialised with the bias; layer-1 k-steps pair feature s (lane-half 0) with F/2+s
  * (lane-half 1); layer-2 k-steps walk the accumulator registers of layer 1; layer 3 is a VALU
- * fmaf chain per lane-half, halves added, then bias). n_hidden == 2 only. */
-void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
-                        const int8_t* x, int32_t H, float* logits) {
+ * fmaf chain per lane-half, halves added, then bias). */
+void orc_mlp_logits_dev_n(const float* params, int32_t F, int32_t HID, int32_t n_hidden,
+                          const int8_t* x, int32_t H, float* logits) {
+    /* any num_hidden_layers (test/policy.jl:9-19): every hidden->hidden layer walks its contraction in the
+     * accumulator-register order of the previous layer's tiles, exactly like layer 2 (k_policy_fwd, DEEP form) */
     const float* W1 = params;
     const float* b1 = W1 + (size_t)HID * F;
-    const float* W2 = b1 + HID;
-    const float* b2 = W2 + (size_t)HID * HID;
-    const float* W3 = b2 + HID;
+    const float* Wh = b1 + HID;                                  /* n_hidden - 1 blocks of (W [HID,HID], b [HID]) */
+    const float* W3 = Wh + (size_t)(n_hidden - 1) * ((size_t)HID * HID + HID);
     const float* b3 = W3 + (size_t)ORC_OUT * HID;
     float* h1 = (float*)malloc(sizeof(float) * (size_t)HID);
     float* h2 = (float*)malloc(sizeof(float) * (size_t)HID);
@@ -412,15 +413,20 @@ void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
             }
             h1[i] = lrelu_f(acc);
         }
-        for (int i = 0; i < HID; ++i) {
-            float acc = b2[i];
-            for (int t = 0; t < T; ++t)
-                for (int r = 0; r < 16; ++r) {
-                    int k0 = dfeat(t, r, 0), k1 = dfeat(t, r, 1);
-                    acc = fmaf(W2[i + (size_t)HID * k0], h1[k0], acc);
-                    acc = fmaf(W2[i + (size_t)HID * k1], h1[k1], acc);
-                }
-            h2[i] = lrelu_f(acc);
+        for (int l = 1; l < n_hidden; ++l) {
+            const float* W2 = Wh + (size_t)(l - 1) * ((size_t)HID * HID + HID);
+            const float* b2 = W2 + (size_t)HID * HID;
+            for (int i = 0; i < HID; ++i) {
+                float acc = b2[i];
+                for (int t = 0; t < T; ++t)
+                    for (int r = 0; r < 16; ++r) {
+                        int k0 = dfeat(t, r, 0), k1 = dfeat(t, r, 1);
+                        acc = fmaf(W2[i + (size_t)HID * k0], h1[k0], acc);
+                        acc = fmaf(W2[i + (size_t)HID * k1], h1[k1], acc);
+                    }
+                h2[i] = lrelu_f(acc);
+            }
+            float* t = h1; h1 = h2; h2 = t;
         }
         for (int o = 0; o < ORC_OUT; ++o) {
             float part[2];
@@ -429,7 +435,7 @@ void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
                 for (int t = 0; t < T; ++t)
                     for (int r = 0; r < 16; ++r) {
                         int k = dfeat(t, r, hh);
-                        acc = fmaf(W3[o + (size_t)ORC_OUT * k], h2[k], acc);
+                        acc = fmaf(W3[o + (size_t)ORC_OUT * k], h1[k], acc);
                     }
                 part[hh] = acc;
             }
@@ -437,6 +443,11 @@ void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
         }
     }
     free(h1); free(h2);
+}
+
+void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
+                        const int8_t* x, int32_t H, float* logits) {
+    orc_mlp_logits_dev_n(params, F, HID, 2, x, H, logits);
 }
 
 /* softmax(logits + mask): subtract max, exp, divide by sum (NNlib semantics);
@@ -536,7 +547,7 @@ void orc_collect_rollouts_tn(orc_env* e, const float* params, int32_t HID, int32
             orc_env_observe_one(e, n, obs);                                   /* :2  state(env) */
             active[idx] = e->active[n];
             if (mode_dev) {
-                orc_mlp_logits_dev(params, F, HID, obs, H, logits);
+                orc_mlp_logits_dev_n(params, F, HID, n_hidden, obs, H, logits);
                 orc_masked_softmax_dev(logits, e->active[n], A, probs);
             } else {
                 orc_mlp_logits_ref(params, F, HID, n_hidden, obs, H, logits);  /* :5 */

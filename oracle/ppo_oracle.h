@@ -89,7 +89,9 @@ void orc_mlp_logits_ref(const float* params, int32_t F, int32_t HID, int32_t n_h
                         const int8_t* x /*[H][F]*/, int32_t H, float* logits /*[H*4] type fastest*/);
 void orc_mlp_logits_f64(const float* params, int32_t F, int32_t HID, int32_t n_hidden,
                         const int8_t* x, int32_t H, double* logits);
-/* device-order fp32 (n_hidden==2 only): the exact fmaf chain order of the gfx950 MFMA kernels */
+/* device-order fp32: the exact fmaf chain order of the gfx950 MFMA kernels (orc_mlp_logits_dev: n_hidden == 2) */
+void orc_mlp_logits_dev_n(const float* params, int32_t F, int32_t HID, int32_t n_hidden,
+                          const int8_t* x, int32_t H, float* logits);
 void orc_mlp_logits_dev(const float* params, int32_t F, int32_t HID,
                         const int8_t* x, int32_t H, float* logits);
 /* softmax(logits + mask) over A = 4H entries; mask from active-quad bits (quad = a/16) */

@@ -28,8 +28,11 @@ def _array_doc(a, dims):
             "data": np.ascontiguousarray(a, "<f4").tobytes()}
 
 
-def _dense_type(act):
-    # Dense{typeof(act), Matrix{Float32}, Vector{Float32}}: the two array types are back-references 9 and 10
+def _dense_type(act, inline=False):
+    # Dense{typeof(act), Matrix{Float32}, Vector{Float32}}: the two array types are back-references 9 and 10 in the
+    # documents BSON.jl wrote for the reference's three-Dense-layer fixtures; `inline` spells them out instead
+    if inline:
+        return _dt(("Flux", "Dense"), [_dt(act), _dt(("Core", "Array"), [_dt(_F32), 2]), _dt(("Core", "Array"), [_dt(_F32), 1])])
     return _dt(("Flux", "Dense"), [_dt(act), {"tag": "backref", "ref": 9}, {"tag": "backref", "ref": 10}])
 
 
@@ -39,9 +42,12 @@ def layer_dims(in_channels, hidden_channels, num_hidden_layers, num_output):
 
 
 def policy_document(params, in_channels, hidden_channels, num_hidden_layers, num_output):
-    """The BSON.jl document of `BSON.@save path policy` for SimplePolicy.Policy (test/policy.jl:1-33)."""
-    if num_hidden_layers != 2:
-        raise ValueError("only Policy(in, hidden, 2, out) documents are reproduced (the reference's fixtures)")
+    """The BSON.jl document of `BSON.@save path policy` for SimplePolicy.Policy (test/policy.jl:1-33).
+    num_hidden_layers == 2 reproduces the reference's fixtures byte for byte (their `_backrefs` table included).  The
+    reference holds no checkpoint of another depth, so for those the shared array datatypes are written inline and
+    `_backrefs` is empty -- the same document without BSON.jl's back-reference compression (parity unpinned: nothing in
+    the reference pins the bytes; the arrays, their order and the struct tags are the ones BSON.jl reads)."""
+    inline = num_hidden_layers != 2
     p = np.ascontiguousarray(params, np.float32)
     dims = layer_dims(in_channels, hidden_channels, num_hidden_layers, num_output)
     if p.size != sum(o * i + o for (o, i) in dims):
@@ -53,14 +59,14 @@ def policy_document(params, in_channels, hidden_channels, num_hidden_layers, num
         off += o * i
         b = p[off:off + o]
         off += o
-        layers.append({"tag": "struct", "type": _dense_type(act),
+        layers.append({"tag": "struct", "type": _dense_type(act, inline),
                        "data": [_array_doc(W, (o, i)), _array_doc(b, (o,)),
                                 {"tag": "struct", "type": _dt(act), "data": []}]})
     chain = {"tag": "struct",
-             "type": _dt(("Flux", "Chain"), [_dt(("Core", "Tuple"), [_dense_type(a) for a in acts])]),
+             "type": _dt(("Flux", "Chain"), [_dt(("Core", "Tuple"), [_dense_type(a, inline) for a in acts])]),
              "data": [{"tag": "tuple", "data": layers}]}
     backrefs = []
-    for _ in range(5):
+    for _ in range(0 if inline else 5):
         backrefs.append(_dt(("Core", "Array"), [_dt(_F32), 2]))
         backrefs.append(_dt(("Core", "Array"), [_dt(_F32), 1]))
     return {"policy": {"tag": "struct", "type": _dt(("Main", "SimplePolicy", "Policy")),

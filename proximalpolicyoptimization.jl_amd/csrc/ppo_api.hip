@@ -369,23 +369,28 @@ int32_t ppo_env_get_internal(ppo_env_t env, int8_t* score, int8_t* degree, int32
 // one of those zeros as a factor (dZ2[pad] = (W3^T dY)[pad] = 0, H1[pad] = 0, dH1[pad] = (W2^T dZ2)[pad] = 0), so Adam
 // (m = v = 0 -> update 0 / (sqrt(0) + eps) = 0) never moves it.  The caller sees its own Policy(F, hidden, 2, 4): the flat
 // Flux-order vectors that cross the ABI (parameters, gradient, Adam moments) have the caller's layout.
-static __host__ __device__ inline int64_t np_of(int64_t F, int64_t hid) { return hid * F + hid + hid * hid + hid + (int64_t)PPO_OUT * hid + PPO_OUT; }
+static __host__ __device__ inline int64_t np_of(int64_t F, int64_t hid, int64_t L = 2) {
+    return hid * F + hid + (L - 1) * (hid * hid + hid) + (int64_t)PPO_OUT * hid + PPO_OUT;
+}
 
-// index of the caller's flat element i (width hu) in the flat vector at width hp
-__device__ __forceinline__ int64_t pad_index(int64_t i, int F, int hu, int hp) {
-    const int64_t uW2 = (int64_t)hu * F + hu, ub2 = uW2 + (int64_t)hu * hu, uW3 = ub2 + hu;
-    const int64_t pW2 = (int64_t)hp * F + hp, pb2 = pW2 + (int64_t)hp * hp, pW3 = pb2 + hp;
+// index of the caller's flat element i (width hu, L hidden layers) in the flat vector at width hp
+__device__ __forceinline__ int64_t pad_index(int64_t i, int F, int hu, int hp, int L) {
+    const int64_t uW2 = (int64_t)hu * F + hu, uper = (int64_t)hu * hu + hu, uW3 = uW2 + (L - 1) * uper;
+    const int64_t pW2 = (int64_t)hp * F + hp, pper = (int64_t)hp * hp + hp, pW3 = pW2 + (L - 1) * pper;
     if (i < (int64_t)hu * F) return (i % hu) + (int64_t)hp * (i / hu);                  // W1[o][k]
     if (i < uW2) return (int64_t)hp * F + (i - (int64_t)hu * F);                        // b1
-    if (i < ub2) { const int64_t e = i - uW2; return pW2 + (e % hu) + (int64_t)hp * (e / hu); }   // W2[o][k]
-    if (i < uW3) return pb2 + (i - ub2);                                               // b2
+    if (i < uW3) {                                                                     // hidden->hidden layer: W[o][k], then b
+        const int64_t lay = (i - uW2) / uper, e = (i - uW2) - lay * uper;
+        if (e < (int64_t)hu * hu) return pW2 + lay * pper + (e % hu) + (int64_t)hp * (e / hu);
+        return pW2 + lay * pper + (int64_t)hp * hp + (e - (int64_t)hu * hu);
+    }
     return pW3 + (i - uW3);                                                            // W3[4][k] (k < hu), b3: b3 follows W3
 }
-__global__ void k_pad_copy(float* __restrict__ user, float* __restrict__ padded, int64_t n_user, int F, int hu, int hp, int to_user) {
+__global__ void k_pad_copy(float* __restrict__ user, float* __restrict__ padded, int64_t n_user, int F, int hu, int hp, int L, int to_user) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_user) return;
     // b3 sits behind W3 in both layouts, but W3 is [4][hid]: the last 4 elements are b3
-    const int64_t pi = (i >= n_user - PPO_OUT) ? (np_of(F, hp) - (n_user - i)) : pad_index(i, F, hu, hp);
+    const int64_t pi = (i >= n_user - PPO_OUT) ? (np_of(F, hp, L) - (n_user - i)) : pad_index(i, F, hu, hp, L);
     if (to_user) user[i] = padded[pi]; else padded[pi] = user[i];
 }
 // host flat vector (caller's layout) <-> device flat vector at the kernels' width
@@ -396,7 +401,7 @@ static int32_t flat_to_device(ppo_policy_s* p, const float* host, float* dev_pad
     PPO_TRY(h2d(tmp.p, host, (size_t)p->np_user));
     HIP_TRY(hipMemsetAsync(dev_padded, 0, (size_t)p->np * sizeof(float), g_stream));
     hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((p->np_user + 255) / 256)), dim3(256), 0, g_stream, tmp.p, dev_padded,
-                       p->np_user, p->F, p->hid_user, p->HID, 0);
+                       p->np_user, p->F, p->hid_user, p->HID, p->L, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(g_stream));
     return PPO_OK;
@@ -406,7 +411,7 @@ static int32_t flat_to_host(ppo_policy_s* p, float* host, const float* dev_padde
     DevBuf<float> tmp;
     PPO_TRY(tmp.alloc((size_t)p->np_user));
     hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((p->np_user + 255) / 256)), dim3(256), 0, g_stream, tmp.p,
-                       const_cast<float*>(dev_padded), p->np_user, p->F, p->hid_user, p->HID, 1);
+                       const_cast<float*>(dev_padded), p->np_user, p->F, p->hid_user, p->HID, p->L, 1);
     HIP_TRY(hipGetLastError());
     return d2h(host, tmp.p, (size_t)p->np_user);
 }
@@ -416,20 +421,24 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_lay
     PPO_TRY(ensure_init());
     ARG_CHECK(out, "policy_create: null out");
     const int32_t hidden = hidden_user <= 128 ? 128 : 256;                  // width of the kernels that run it
-    if (num_hidden_layers != 2 || out_per_edge != PPO_OUT || hidden_user < 1 || hidden_user > 256 ||
-        !(F == 72 || (F == 216 && hidden == 128))) {
-        ppo_set_error("policy_create: the gfx950 kernels cover Policy(72, 1..256, 2, 4) and Policy(216, 1..128, 2, 4) "
-                      "(test/test_square_mesh.jl:29, test/output/*.bson, BASELINE config 2); hidden widths other than "
-                      "128 / 256 run zero-padded on the next wider kernel");
+    if (num_hidden_layers < 1 || num_hidden_layers > 4 || out_per_edge != PPO_OUT || hidden_user < 1 || hidden_user > 256 ||
+        !(F == 72 || F == 216)) {
+        ppo_set_error("policy_create: the gfx950 kernels cover Policy(F, hidden, num_hidden_layers, 4) with F in {72, 216}, "
+                      "hidden in 1..256 and num_hidden_layers in 1..4 (test/policy.jl:9-19, test/test_square_mesh.jl:29, "
+                      "test/output/*.bson, BASELINE config 2); hidden widths other than 128 / 256 run zero-padded on the "
+                      "next wider kernel; out must be the quad game's 4 actions per edge (test/quad_game_utilities.jl:95)");
         return PPO_ERR_UNSUPPORTED;
     }
+    const int32_t NL2 = num_hidden_layers - 1;
     ppo_policy_s* p = new ppo_policy_s();
     p->F = F; p->HID = hidden; p->L = num_hidden_layers; p->OUT = out_per_edge;
-    p->hid_user = hidden_user; p->np_user = np_of(F, hidden_user);
-    p->np = np_of(F, hidden);
+    p->hid_user = hidden_user; p->np_user = np_of(F, hidden_user, num_hidden_layers);
+    p->np = np_of(F, hidden, num_hidden_layers);
     int32_t s = PPO_OK;
-    if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F + PPO_PACK_PAD)) || (s = p->w2p.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) ||
-        (s = p->w2tp.alloc((size_t)hidden * hidden + PPO_PACK_PAD)) || (s = p->b1p.alloc(hidden)) || (s = p->b2p.alloc(hidden)) ||
+    if ((s = p->params.alloc(p->np)) || (s = p->w1p.alloc((size_t)hidden * F + PPO_PACK_PAD)) ||
+        (s = p->w2p.alloc((size_t)NL2 * hidden * hidden + PPO_PACK_PAD)) ||
+        (s = p->w2tp.alloc((size_t)NL2 * hidden * hidden + PPO_PACK_PAD)) || (s = p->b1p.alloc(hidden)) ||
+        (s = p->b2p.alloc((size_t)(NL2 > 0 ? NL2 : 1) * hidden)) ||
         (s = p->w3p.alloc((size_t)hidden * PPO_OUT)) || (s = p->b3.alloc(PPO_OUT)) || (s = p->grad.alloc(p->np + 2)) ||
         (s = p->err.alloc(1))) { delete p; return s; }
     (void)hipMemsetAsync(p->params.p, 0, p->np * 4, g_stream);
@@ -447,6 +456,10 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_lay
 int32_t ppo_policy_set_dtype(ppo_policy_t pol, int32_t dtype) {
     ARG_CHECK(pol, "policy_set_dtype: null policy");
     ARG_CHECK(dtype == PPO_DTYPE_F32 || dtype == PPO_DTYPE_BF16, "policy_set_dtype: dtype must be PPO_DTYPE_F32 or PPO_DTYPE_BF16");
+    if (dtype == PPO_DTYPE_BF16 && (pol->L != 2 || pol->F != 72)) {
+        ppo_set_error("policy_set_dtype: the bf16 kernels cover Policy(72, hidden, 2, 4) only");
+        return PPO_ERR_UNSUPPORTED;
+    }
     if (dtype == PPO_DTYPE_BF16 && !pol->w1b.p) {
         const size_t HID = pol->HID, KS1 = bf16_ks1(pol->F);
         PPO_TRY(pol->w1b.alloc(HID * KS1 * 16)); PPO_TRY(pol->w2b.alloc(HID * HID)); PPO_TRY(pol->w2tb.alloc(HID * HID));
@@ -890,10 +903,12 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
     if (compact) PPO_TRY(p->xs.alloc((size_t)std::max(B, p->cap_tiles) * 32 * p->F));
     if (B <= p->cap_tiles) return PPO_OK;
     const size_t NT = p->HID / 32;
-    PPO_TRY(p->act1.alloc((size_t)B * NT * 1024)); PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
+    PPO_TRY(p->act1.alloc((size_t)B * NT * 1024));
+    if (p->L >= 2) PPO_TRY(p->act2.alloc((size_t)B * NT * 1024));
+    if (p->L > 2) PPO_TRY(p->actm.alloc((size_t)(p->L - 2) * B * NT * 1024));       // hidden layers between the first and the last
     PPO_TRY(p->dY.alloc((size_t)B * 128)); PPO_TRY(p->loss_terms.alloc((size_t)B * 2));
     // one gradient slab per backward workgroup: 256, or 512 where two workgroups share a CU (fp32 HID = 128, F = 72)
-    PPO_TRY(p->slabs.alloc((size_t)((p->HID == 128 && p->F == 72) ? 512 : 256) * slab_floats(p->F, p->HID)));
+    PPO_TRY(p->slabs.alloc((size_t)((p->HID == 128 && p->F == 72) ? 512 : 256) * slab_floats(p->F, p->HID, p->L)));
     PPO_TRY(p->idx.alloc((size_t)B));
     p->cap_tiles = B;
     return PPO_OK;
@@ -916,10 +931,16 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew, adv));
     // small minibatches: three-product backward (no per-workgroup gradient slabs); otherwise the fused kernel
     int32_t bs = PPO_ERR_UNSUPPORTED;
-    if (B * (ro->H / 32) <= g_bwd_small_max_tiles && pol->dtype == PPO_DTYPE_F32) {
-        const size_t frag = (size_t)B * (ro->H / 32) * (pol->HID / 32) * 1024;     // dZ2 / dZ1 in fragment order, like act1 / act2
-        PPO_TRY(pol->dz2f.alloc(frag)); PPO_TRY(pol->dz1f.alloc(frag));
+    // the fused kernel is the num_hidden_layers == 2 shape with all its weight gradients resident (and F = 216 at HID = 256
+    // does not fit its LDS): every other policy takes the layer-looped three-product form at any minibatch size
+    const bool fused_ok = pol->L == 2 && !(pol->F == 216 && pol->HID == 256);
+    if ((B * (ro->H / 32) <= g_bwd_small_max_tiles || !fused_ok) && pol->dtype == PPO_DTYPE_F32) {
+        const size_t frag = (size_t)pol->cap_tiles * (pol->HID / 32) * 1024;     // dZ in fragment order, like act1 / act2
+        PPO_TRY(pol->dz1f.alloc(frag));
+        if (pol->L >= 2) PPO_TRY(pol->dz2f.alloc(frag));
+        if (pol->L > 2) PPO_TRY(pol->dzm.alloc((size_t)(pol->L - 2) * frag));
         bs = launch_policy_bwd_small(pol, ro, idx_dev, B);
+        if (bs == PPO_ERR_UNSUPPORTED && !fused_ok) { ppo_set_error("step_batch!: no backward kernel for this policy / state shape"); return bs; }
     }
     if (bs != PPO_OK && bs != PPO_ERR_UNSUPPORTED) return bs;
     if (bs == PPO_ERR_UNSUPPORTED) PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));

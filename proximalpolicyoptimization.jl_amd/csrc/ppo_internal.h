@@ -87,22 +87,26 @@ struct ppo_env_s {
 #define PPO_BWD_Z2ROW_AT(HID) ((HID) <= PPO_BWD_Z2ROW_MAX_HID)
 
 struct ppo_policy_s {
-    int32_t F, HID, L, OUT;            // HID: the width the kernels run (128 or 256)
+    int32_t F, HID, L, OUT;            // HID: the width the kernels run (128 or 256); L = hidden layers (test/policy.jl:9-19):
+                                       // Dense(F,HID) + (L-1) x Dense(HID,HID) + Dense(HID,OUT).  L == 2 runs the fused
+                                       // kernels; L in {1, 3, 4} the layer-looped ("deep") forms of the same kernels
     int32_t hid_user = 0;              // hidden_channels the caller asked for (<= HID): the missing units are zero-padded
     int64_t np_user = 0;               // parameter count of the caller's Policy (what crosses the ABI)
     int64_t np;                        // parameter count at width HID (device buffers, all-reduce)
     // canonical flat parameters (Flux order) + packed MFMA-fragment copies
     DevBuf<float> params;              // [np]
-    DevBuf<float> w1p, w2p, w2tp;      // A-operand fragment order
-    DevBuf<float> b1p, b2p, w3p, b3;   // accumulator-init / VALU packs
+    DevBuf<float> w1p, w2p, w2tp;      // A-operand fragment order; w2p / w2tp: the L-1 hidden->hidden layers back to back (HID*HID each)
+    DevBuf<float> b1p, b2p, w3p, b3;   // accumulator-init / VALU packs; b2p: L-1 x HID
     // bf16 compute mode (ppo_policy_set_dtype): bf16 fragment streams of the same parameters, rewritten by k_adam
     int32_t dtype = 0;                 // PPO_DTYPE_F32 / PPO_DTYPE_BF16
     DevBuf<uint16_t> w1b, w2b, w2tb;   // [HID/32][KS][64][8] A-operand fragments of v_mfma_f32_32x32x16_bf16
     DevBuf<uint16_t> w3c, w3tb;        // layer 3 forward (compact rows 0..3) / backward ([HID][4])
     DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
     // training workspace
-    DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4
-    DevBuf<float> dz2f, dz1f;          // small-minibatch backward: dZ2 / dZ1 in fragment order (like act1 / act2)
+    DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4: the FIRST and the LAST hidden layer
+    DevBuf<float> actm;                // L > 2: the L-2 hidden layers in between, [L-2][tiles]... back to back
+    DevBuf<float> dz2f, dz1f;          // three-product backward: dZ of the last / first hidden layer in fragment order (like act2 / act1)
+    DevBuf<float> dzm;                 // L > 2: dZ of the layers in between, like actm
     DevBuf<float> dY;                  // [tiles][32][4]
     DevBuf<double> loss_terms;         // [tiles][2]
     DevBuf<float> slabs;               // [nwg][slab]
@@ -171,9 +175,11 @@ int32_t disk_sink_finish(ppo_rollouts_s* ro);                // after the return
 void disk_sink_destroy(DiskSink* s);
 
 // ---------------------------------------------------------------- packed layout sizes
-static inline size_t slab_floats(int F, int HID) {
+// one gradient slab: [dW of the L-1 hidden->hidden layers][dW1, input padded to 32][db1][db of the L-1 layers][dW3][db3 + pad]
+// (L == 2: exactly the round-1 layout W2, W1, b1, b2, W3, b3)
+static inline size_t slab_floats(int F, int HID, int L = 2) {
     const int FP = ((F + 31) / 32) * 32;
-    return (size_t)HID * HID + (size_t)HID * FP + (size_t)HID * 2 + (size_t)HID * PPO_OUT + 64;
+    return (size_t)(L - 1) * HID * HID + (size_t)HID * FP + (size_t)HID * L + (size_t)HID * PPO_OUT + 64;
 }
 
 // ---------------------------------------------------------------- kernel launchers (defined in the .hip files)

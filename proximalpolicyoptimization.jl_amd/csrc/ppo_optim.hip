@@ -4,16 +4,18 @@
 #include "ppo_internal.h"
 #include "ppo_device.h"
 
+// flat Flux-order parameter vector of Policy(F, HID, NL, 4) (test/policy.jl:9-19): W1, b1, then the NL - 1 hidden->hidden
+// layers (W, b) back to back -- layer l at offW2 + l * (HID*HID + HID) -- then W3, b3
 struct ParamLayout {
-    int F, HID, NT, FP, NI;
-    int64_t offW1, offb1, offW2, offb2, offW3, offb3, np;
+    int F, HID, NT, FP, NI, NL2;                // NL2 = hidden->hidden layers (num_hidden_layers - 1)
+    int64_t offW1, offb1, offW2, offW3, offb3, np;
 };
 
 static ParamLayout layout_of(const ppo_policy_s* p) {
     ParamLayout L;
-    L.F = p->F; L.HID = p->HID; L.NT = p->HID / 32; L.FP = ((p->F + 31) / 32) * 32; L.NI = L.FP / 32;
+    L.F = p->F; L.HID = p->HID; L.NT = p->HID / 32; L.FP = ((p->F + 31) / 32) * 32; L.NI = L.FP / 32; L.NL2 = p->L - 1;
     L.offW1 = 0; L.offb1 = (int64_t)p->HID * p->F; L.offW2 = L.offb1 + p->HID;
-    L.offb2 = L.offW2 + (int64_t)p->HID * p->HID; L.offW3 = L.offb2 + p->HID;
+    L.offW3 = L.offW2 + (int64_t)L.NL2 * ((int64_t)p->HID * p->HID + p->HID);
     L.offb3 = L.offW3 + (int64_t)PPO_OUT * p->HID; L.np = L.offb3 + PPO_OUT;
     return L;
 }
@@ -37,8 +39,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     __shared__ float part[4][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const size_t e = (size_t)blockIdx.x * 64 + el;
-    const size_t nW2 = (size_t)L.HID * L.HID, nW1 = (size_t)L.HID * L.FP;
-    const size_t total = nW2 + nW1 + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
+    const size_t nW2l = (size_t)L.HID * L.HID, nW2 = (size_t)L.NL2 * nW2l, nW1 = (size_t)L.HID * L.FP;
+    const size_t total = nW2 + nW1 + (size_t)L.HID * (1 + L.NL2) + (size_t)L.HID * 4 + 4;
     // fixed summation order: 8 interleaved partial sums per slab group, a fixed tree, then the 4 groups in order
     float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nwg = (e < nW2 + nW1) ? nwg_w : nwg_s;
@@ -56,10 +58,12 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     const float s = (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
     int64_t canon = -1;
     if (e < nW2) {
-        const int lane = (int)(e & 63), r = (int)((e >> 6) & 15);
-        const int tile = (int)(e >> 10), kt = tile % L.NT, ft = tile / L.NT;
+        const int lay = (int)(e / nW2l);
+        const size_t el2 = e - (size_t)lay * nW2l;
+        const int lane = (int)(el2 & 63), r = (int)((el2 >> 6) & 15);
+        const int tile = (int)(el2 >> 10), kt = tile % L.NT, ft = tile / L.NT;
         const int f = dfeat(ft, r, lane >> 5), k = 32 * kt + (lane & 31);
-        canon = L.offW2 + f + (int64_t)L.HID * k;
+        canon = L.offW2 + (int64_t)lay * ((int64_t)nW2l + L.HID) + f + (int64_t)L.HID * k;
     } else if (e < nW2 + nW1) {
         const size_t e1 = e - nW2;
         const int lane = (int)(e1 & 63), r = (int)((e1 >> 6) & 15);
@@ -69,8 +73,9 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     } else {
         size_t e2 = e - nW2 - nW1;
         if (e2 < (size_t)L.HID) canon = L.offb1 + (int64_t)e2;
-        else if ((e2 -= L.HID) < (size_t)L.HID) canon = L.offb2 + (int64_t)e2;
-        else if ((e2 -= L.HID) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
+        else if ((e2 -= L.HID) < (size_t)L.HID * L.NL2)         // bias of hidden->hidden layer e2 / HID, behind its weights
+            canon = L.offW2 + (int64_t)(e2 / L.HID) * ((int64_t)nW2l + L.HID) + (int64_t)nW2l + (int64_t)(e2 % L.HID);
+        else if ((e2 -= (size_t)L.HID * L.NL2) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
         else canon = L.offb3 + (int64_t)(e2 - (size_t)L.HID * 4);
     }
     if (canon >= 0) grad[canon] = s;
@@ -131,18 +136,26 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
     } else if (i < L.offW2) {
         const int f = (int)(i - L.offb1), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         P.b1p[((f >> 5) * 2 + hh) * 16 + r] = x;
-    } else if (i < L.offb2) {                            // W2[f][k]
-        const int64_t e = i - L.offW2;
+    } else if (i < L.offW3) {                            // hidden->hidden layer `lay`: W[f][k], then its bias
+        const int64_t per = (int64_t)HID * HID + HID;
+        const int lay = (int)((i - L.offW2) / per);
+        const int64_t e = (i - L.offW2) - (int64_t)lay * per;
+        if (e >= (int64_t)HID * HID) {                   // bias: accumulator-init order, like b1
+            const int f = (int)(e - (int64_t)HID * HID), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+            P.b2p[(size_t)lay * HID + ((f >> 5) * 2 + hh) * 16 + r] = x;
+            return;
+        }
+        const size_t lo = (size_t)lay * HID * HID;       // the layers' fragment streams sit back to back
         const int f = (int)(e % HID), k = (int)(e / HID);
-        {   // forward A operand: out f, contraction in layer-1 accumulator-register order
+        {   // forward A operand: out f, contraction in the previous layer's accumulator-register order
             const int kk = k & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
             const int s = 16 * (k >> 5) + r;
-            P.w2p[((size_t)((f >> 5) * (HID / 8) + (s >> 2)) * 64 + (f & 31) + 32 * hh) * 4 + (s & 3)] = x;
+            P.w2p[lo + ((size_t)((f >> 5) * (HID / 8) + (s >> 2)) * 64 + (f & 31) + 32 * hh) * 4 + (s & 3)] = x;
         }
-        {   // backward A operand (W2^T): out k, contraction slot (group g, component e, lane half hh) of feature f
+        {   // backward A operand (W^T): out k, contraction slot (group g, component e, lane half hh) of feature f
             const bool zrow = PPO_BWD_Z2ROW_AT(HID);
             const int g = f >> 3, hh = zrow ? (f >> 2) & 1 : f & 1, e = zrow ? f & 3 : (f >> 1) & 3;   // f = 8g + 4hh + e  |  8g + 2e + hh
-            P.w2tp[((size_t)((k >> 5) * (HID / 8) + g) * 64 + (k & 31) + 32 * hh) * 4 + e] = x;
+            P.w2tp[lo + ((size_t)((k >> 5) * (HID / 8) + g) * 64 + (k & 31) + 32 * hh) * 4 + e] = x;
         }
         if (P.w2b) {
             const uint16_t xb = to_bf16(x);
@@ -153,9 +166,6 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             // operand is read straight from the row-major dZ2 image
             P.w2tb[((size_t)((k >> 5) * (HID / 16) + (f >> 4)) * 64 + (k & 31) + 32 * ((f >> 3) & 1)) * 8 + (f & 7)] = xb;
         }
-    } else if (i < L.offW3) {
-        const int f = (int)(i - L.offb2), kk = f & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
-        P.b2p[((f >> 5) * 2 + hh) * 16 + r] = x;
     } else if (i < L.offb3) {                            // W3[oo][k]
         const int64_t e = i - L.offW3;
         const int oo = (int)(e & 3), k = (int)(e >> 2);
@@ -226,10 +236,10 @@ int32_t launch_pack_params(ppo_policy_s* p) {
 // slab reduction + (one extra block) loss-term reduction in a single launch
 int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight) {
     ParamLayout L = layout_of(p);
-    const size_t total = (size_t)L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * 2 + (size_t)L.HID * 4 + 4;
+    const size_t total = (size_t)L.NL2 * L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * (1 + L.NL2) + (size_t)L.HID * 4 + 4;
     ProfScope ps("k_grad_reduce");
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 63) / 64) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
-                       slab_floats(p->F, p->HID), p->nwg_bwd, p->nwg_small ? p->nwg_small : p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
+                       slab_floats(p->F, p->HID, p->L), p->nwg_bwd, p->nwg_small ? p->nwg_small : p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
                        entropy_weight);
     HIP_TRY(hipGetLastError());
     return PPO_OK;

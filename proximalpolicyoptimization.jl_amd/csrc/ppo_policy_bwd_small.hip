@@ -29,6 +29,10 @@ struct BwdSmallArgs {
     float4* dz2f; float4* dz1f;                             // [tile][feature tile][4][64] float4, like act1 / act2
     float* slabs; size_t slab_stride;
     int ksplit;                                             // K-slices of k_policy_wgrad
+    // any num_hidden_layers (test/policy.jl:9-19): L hidden layers, actl[l] / dzl[l] = saved output / dZ of hidden layer l
+    // (l = 0 first, L - 1 last; L == 2: {act1, act2} / {dz1f, dz2f}), w2tp = the L - 1 packed W^T streams back to back
+    int L;
+    const float4* actl[4]; float4* dzl[4];
 };
 
 // ---------------------------------------------------------------------------------------------- backward-data
@@ -220,6 +224,201 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data(BwdSmallArgs a) 
     if (tid < 4) sb3[tid] = db3;
 }
 
+// ---------------------------------------------------------------------------------------------- backward-data, any depth
+// The same pass for Policy(F, HID, L, 4) with L = 1, 3 or 4 hidden layers (test/policy.jl:9-19): per tile
+//   dZ_{L-1} = (W3^T dY) . lrelu'(H_{L-1});   for l = L-2 .. 0:  dH_l = W_{l+1}^T dZ_{l+1} (MFMA),  dZ_l = dH_l . lrelu'(H_l)
+// with dZ ping-ponged between two LDS tiles in the B-operand form of the next product (one workgroup barrier per layer:
+// a layer reads tile `cur` from every wave and writes its own feature tile of `cur ^ 1`), every dZ_l stored in fragment
+// order for k_policy_wgrad, and the bias / W3 gradients summed on the VALU as in k_policy_bwd_data.  Correctness first:
+// the per-layer activation fetch is not hidden behind the previous layer's MFMAs.
+template <int F, int HID>
+__global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_data_deep(BwdSmallArgs a) {
+    constexpr int NT = HID / 32, LD = SB_LD, S4 = HID / 8, FP = ((F + 31) / 32) * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool Z2R = PPO_BWD_Z2ROW_AT(HID);
+    constexpr int RS = HID + 4, Z2SZ = Z2R ? 32 * RS : HID * LD;
+    float* const sZ0 = smem;                    // dZ tile A  (Z2R: [32][RS] row-major; else [HID][LD] transposed)
+    float* const sZ1 = sZ0 + Z2SZ;              // dZ tile B
+    float* const sH = sZ1 + Z2SZ;               // [HID][LD] H_{L-1}^T (dW3 sums)
+    float* const sDY = sH + HID * LD;           // [32][4]
+    float* const sW3 = sDY + 32 * 4;            // [HID][4]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = a.L;
+    float db[4] = {0.f, 0.f, 0.f, 0.f}, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
+        const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
+    }
+    __syncthreads();
+    const unsigned fb = (unsigned)(32 * w + 4 * h);
+    // write this lane's 16 dZ values (register 4q + e <-> feature fb + e + 8q, row j) into a dZ tile in B-operand form
+    auto put_z = [&](float* sZ, int q, const float (&z)[4]) {
+        if constexpr (Z2R) *reinterpret_cast<float4*>(sZ + j * RS + fb + 8 * q) = make_float4(z[0], z[1], z[2], z[3]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sZ[(fb + e + 8 * q) * LD + j] = z[e];
+        }
+    };
+    // sum over rows [16h, 16h + 16) of feature 32w + j of a dZ tile
+    auto row_sum = [&](const float* sZ) {
+        float s = 0.f;
+        if constexpr (Z2R) {
+            const float* g = sZ + (16 * h) * RS + 32 * w + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += g[r * RS];
+        } else {
+            const float* g = sZ + (32 * w + j) * LD + 16 * h;
+#pragma unroll
+            for (int rc = 0; rc < 16; rc += 4) { const float4 z4 = *reinterpret_cast<const float4*>(g + rc); s += z4.x; s += z4.y; s += z4.z; s += z4.w; }
+        }
+        return s;
+    };
+    auto add_db = [&](int l, float s) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) db[k] += (k == l) ? s : 0.0f;
+    };
+    for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        // ---- top layer: dZ_{L-1} of feature tile w
+        float4 vt[4];
+        {
+            const float4* st = a.actl[L - 1] + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vt[q] = st[q * 64];
+        }
+        const float4 dy = a.dY[(size_t)tile * 32 + j];
+        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        f32x16 dh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = 0.0f;
+        dh = __builtin_amdgcn_mfma_f32_32x32x2f32(sW3[(32 * w + j) * 4 + h], h ? dy.y : dy.x, dh, 0, 0, 0);
+        dh = __builtin_amdgcn_mfma_f32_32x32x2f32(sW3[(32 * w + j) * 4 + 2 + h], h ? dy.w : dy.z, dh, 0, 0, 0);
+        {
+            float4* const zo = a.dzl[L - 1] + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float hv[4] = {vt[q].x, vt[q].y, vt[q].z, vt[q].w};
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    z[e] = dh[4 * q + e] * (hv[e] > 0.0f ? 1.0f : 0.01f);
+                    sH[(fb + e + 8 * q) * LD + j] = hv[e];
+                }
+                put_z(sZ0, q, z);
+                zo[q * 64] = make_float4(z[0], z[1], z[2], z[3]);
+            }
+        }
+        __syncthreads();
+        {   // small gradients of the top layer: db_{L-1}, dW3, db3 (feature 32w + j, rows 16h .. 16h+15)
+            add_db(L - 1, row_sum(sZ0));
+            const float* gh = sH + (32 * w + j) * LD + 16 * h;
+            const float* gy = sDY + 64 * h;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll 1
+            for (int rc = 0; rc < 16; rc += 4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
+                const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 y = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
+                    d0 = fmaf(y.x, hv[i], d0); d1 = fmaf(y.y, hv[i], d1); d2 = fmaf(y.z, hv[i], d2); d3 = fmaf(y.w, hv[i], d3);
+                }
+            }
+            dw3[0] += d0; dw3[1] += d1; dw3[2] += d2; dw3[3] += d3;
+            if (tid < 4) {
+                float s = 0.f;
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                db3 += s;
+            }
+        }
+        // ---- the layers below: dH_l = W_{l+1}^T dZ_{l+1}, dZ_l = dH_l . lrelu'(H_l)
+        int cur = 0;
+#pragma unroll 1
+        for (int l = L - 2; l >= 0; --l) {
+            const float* const sZc = cur ? sZ1 : sZ0;
+            float* const sZn = cur ? sZ0 : sZ1;
+            float4 vl[4];
+            {
+                const float4* sl = a.actl[l] + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vl[q] = sl[q * 64];
+            }
+            const float4* const w2t = a.w2tp + (size_t)l * (HID * HID / 4) + (size_t)w * S4 * 64 + lane;   // wave w's tile of W_{l+1}^T
+            constexpr int PF = 4;
+            static_assert(S4 % (2 * PF) == 0, "ring sets");
+            float4 ringA[PF], ringB[PF];
+#pragma unroll
+            for (int g = 0; g < PF; ++g) ringA[g] = w2t[(size_t)g * 64];
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* bz = Z2R ? sZc + j * RS + 4 * h : sZc + h * LD + j;
+            auto mfma_set = [&](const float4 (&rg)[PF]) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    float b[4];
+                    if constexpr (Z2R) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bz + 8 * u);
+                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
+                }
+                bz += Z2R ? 8 * PF : 8 * PF * LD;
+            };
+            const float4* wn = w2t + (size_t)PF * 64;
+#pragma unroll 1
+            for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringB[u] = wn[(size_t)u * 64];
+                wn += (size_t)PF * 64;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringA[u] = wn[(size_t)u * 64];      // next stream's head / tail padding covers the over-read
+                wn += (size_t)PF * 64;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float4* const zo = a.dzl[l] + ((size_t)tile * NT + w) * 4 * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float hv[4] = {vl[q].x, vl[q].y, vl[q].z, vl[q].w};
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = acc[4 * q + e] * (hv[e] > 0.0f ? 1.0f : 0.01f);
+                put_z(sZn, q, z);
+                zo[q * 64] = make_float4(z[0], z[1], z[2], z[3]);
+            }
+            __syncthreads();
+            add_db(l, row_sum(sZn));
+            cur ^= 1;
+        }
+        __syncthreads();                                              // the next tile's top layer rewrites sZ0 / sH / sDY
+    }
+    // small-gradient tail of slab blockIdx.x: [db of hidden layer 0][db of layers 1 .. L-1][dW3][db3]
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride + (size_t)(L - 1) * HID * HID + (size_t)HID * FP;
+    float* sw3 = slab + (size_t)L * HID; float* sb3 = sw3 + HID * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) db[k] += __shfl_xor(db[k], 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dw3[i] += __shfl_xor(dw3[i], 32);
+    if (h == 0) {
+        const int f = 32 * w + j;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < L) slab[(size_t)k * HID + f] = db[k];
+        *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(dw3[0], dw3[1], dw3[2], dw3[3]);
+    }
+    if (tid < 4) sb3[tid] = db3;
+}
+
 // ---------------------------------------------------------------------------------------------- weight gradients
 // wave-private transposed tile: fragment (lane = row, registers = 16 features) -> [feature][LD rows]
 __device__ __forceinline__ void frag_to_lds(float* buf, const float4 (&v)[4], int j, int h) {
@@ -243,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* const bufA = smem + (size_t)v * WT * TILE;                  // wave-private: A tiles first, then the B tiles
-    const int block = blockIdx.x % (NB2 + NB1), slice = blockIdx.x / (NB2 + NB1);
+    const int NBH = (a.L - 1) * NB2;                                   // dW blocks of the L - 1 hidden->hidden layers
+    const int block = blockIdx.x % (NBH + NB1), slice = blockIdx.x / (NBH + NB1);
     const int64_t per = (a.B + a.ksplit - 1) / a.ksplit;
     const int64_t t0 = (int64_t)slice * per, t1 = (t0 + per < a.B) ? t0 + per : a.B;
     float* slab = a.slabs + (size_t)slice * a.slab_stride;             // one partial per K-slice: the four waves' sums meet in LDS
@@ -254,11 +454,15 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
         return ((red0[(size_t)0 * WT * TILE + r * 64 + lane] + red0[(size_t)1 * WT * TILE + r * 64 + lane]) +
                 red0[(size_t)2 * WT * TILE + r * 64 + lane]) + red0[(size_t)3 * WT * TILE + r * 64 + lane];
     };
-    float* sW2 = slab;
-    float* sW1 = slab + (size_t)HID * HID;
-    if (block < NB2) {
-        // ---------------- dW2 block: f-tiles 2fb, 2fb+1 x k-tiles 2kb, 2kb+1
-        const int fbk = block / (NT / 2), kbk = block % (NT / 2);
+    float* sW1 = slab + (size_t)(a.L - 1) * HID * HID;
+    if (block < NBH) {
+        // ---------------- dW block of hidden->hidden layer m (hidden layer m -> m + 1): dW = dZ_{m+1} H_m^T,
+        // f-tiles 2fb, 2fb+1 x k-tiles 2kb, 2kb+1
+        const int m = block / NB2, blk = block % NB2;
+        float* sW2 = slab + (size_t)m * HID * HID;
+        const float4* const dz_hi = a.dzl[m + 1];
+        const float4* const act_lo = a.actl[m];
+        const int fbk = blk / (NT / 2), kbk = blk % (NT / 2);
         f32x16 acc[2][2];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -273,8 +477,8 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    fa[x][q] = a.dz2f[((size_t)t * NT + (2 * fbk + x)) * 4 * 64 + q * 64 + lane];
-                    fbv[x][q] = a.act1[((size_t)t * NT + (2 * kbk + x)) * 4 * 64 + q * 64 + lane];
+                    fa[x][q] = dz_hi[((size_t)t * NT + (2 * fbk + x)) * 4 * 64 + q * 64 + lane];
+                    fbv[x][q] = act_lo[((size_t)t * NT + (2 * kbk + x)) * 4 * 64 + q * 64 + lane];
                 }
         };
         if (t0 + v < t1) fetch(t0 + v);
@@ -319,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
         }
     } else {
         // ---------------- dW1 block: k-tile kb x all NI input tiles (columns >= F are zero padding)
-        const int kbk = block - NB2;
+        const int kbk = block - NBH;
         float* const bufB = bufA + TILE;
         f32x16 acc[NI];
 #pragma unroll
@@ -331,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
         uint32_t xd[XPL];
         auto fetch = [&](int64_t t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fa[q] = a.dz1f[((size_t)t * NT + kbk) * 4 * 64 + q * 64 + lane];
+            for (int q = 0; q < 4; ++q) fa[q] = a.dzl[0][((size_t)t * NT + kbk) * 4 * 64 + q * 64 + lane];
             const int sidx = a.x_by_tile ? 0 : a.idx[t / a.tps];
             const uint32_t* xs = reinterpret_cast<const uint32_t*>(
                 a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
@@ -385,25 +589,30 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
 template <int F, int HID>
 static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     constexpr int NT = HID / 32, NI = (F + 31) / 32, WT = (1 + NI > 4) ? 1 + NI : 4;
-    const size_t lds_data = sizeof(float) * ((PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * SB_LD) + (size_t)2 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
+    const size_t z2 = PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * SB_LD;
+    const size_t lds_data = sizeof(float) * (z2 + (size_t)2 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
+    const size_t lds_deep = sizeof(float) * (2 * z2 + (size_t)HID * SB_LD + 32 * 4 + (size_t)HID * 4);
     const size_t lds_w = sizeof(float) * (size_t)4 * WT * 32 * SB_LD;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_data));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data_deep<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_deep));
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_wgrad<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
         attr_set = true;
     }
     const int nwg = (int)(a.B < 256 ? a.B : 256);
-    constexpr int blocks = (NT / 2) * (NT / 2) + NT;
+    const int blocks = (a.L - 1) * (NT / 2) * (NT / 2) + NT;
     // K-slices: two workgroups per CU over the block list, all resident at once (a partial second round costs a whole one)
     int ks = 512 / blocks;
+    if (ks < 1) ks = 1;
     if ((int64_t)ks > a.B) ks = (int)a.B;
     a.ksplit = ks;
     p->nwg_bwd = ks;                 // slabs holding weight-gradient partials (one per K-slice)
     p->nwg_small = nwg;              // slabs holding the small-gradient tails
     {
         ProfScope ps("k_policy_bwd_data");
-        hipLaunchKernelGGL((k_policy_bwd_data<F, HID>), dim3(nwg), dim3(HID * 2), lds_data, ppo_stream(), a);
+        if (a.L == 2) hipLaunchKernelGGL((k_policy_bwd_data<F, HID>), dim3(nwg), dim3(HID * 2), lds_data, ppo_stream(), a);
+        else hipLaunchKernelGGL((k_policy_bwd_data_deep<F, HID>), dim3(nwg), dim3(HID * 2), lds_deep, ppo_stream(), a);
     }
     {
         ProfScope ps("k_policy_wgrad");
@@ -415,7 +624,7 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
 
 // PPO_ERR_UNSUPPORTED (no error text): shape or size not covered -> the caller runs the fused kernel
 int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
-    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || !p->dz2f.p || !p->dz1f.p) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || !p->dz1f.p || (p->L >= 2 && !p->dz2f.p) || (p->L > 2 && !p->dzm.p)) return PPO_ERR_UNSUPPORTED;
     BwdSmallArgs a;
     a.tps = ro->H / 32;
     a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
@@ -423,9 +632,19 @@ int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
     a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.dz2f = (float4*)p->dz2f.p; a.dz1f = (float4*)p->dz1f.p;
-    a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID, p->L);
     a.ksplit = 1;
-    if (p->HID == 256) return launch_small<72, 256>(p, a);
-    if (p->HID == 128) return launch_small<72, 128>(p, a);
+    a.L = p->L;
+    const size_t lstride = (size_t)p->cap_tiles * (p->HID / 32) * 256;             // float4 per saved layer
+    for (int l = 0; l < 4; ++l) { a.actl[l] = nullptr; a.dzl[l] = nullptr; }
+    for (int l = 0; l < p->L; ++l) {
+        const bool first = l == 0, last = l == p->L - 1;
+        a.actl[l] = first ? (const float4*)p->act1.p : (last ? (const float4*)p->act2.p : (const float4*)p->actm.p + (size_t)(l - 1) * lstride);
+        a.dzl[l] = first ? (float4*)p->dz1f.p : (last ? (float4*)p->dz2f.p : (float4*)p->dzm.p + (size_t)(l - 1) * lstride);
+    }
+    if (p->F == 72 && p->HID == 256) return launch_small<72, 256>(p, a);
+    if (p->F == 72 && p->HID == 128) return launch_small<72, 128>(p, a);
+    if (p->F == 216 && p->HID == 256) return launch_small<216, 256>(p, a);
+    if (p->F == 216 && p->HID == 128) return launch_small<216, 128>(p, a);
     return PPO_ERR_UNSUPPORTED;
 }

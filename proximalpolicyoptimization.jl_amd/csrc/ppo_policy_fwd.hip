@@ -55,7 +55,14 @@ struct FwdCfg { static constexpr int WPS = (HID >= 256 || F > 128) ? 1 : PPO_FWD
 
 // TPS = 32-row tiles per state (H = 32*TPS half-edges, A = 128*TPS actions): the wave walks the tiles of its
 // state one after the other, keeps the 4*TPS logits per lane, and runs softmax / sampling / loss once per state.
-template <int F, int HID, int MODE, int TPS>
+// DEEP = 1: Policy(F, HID, num_hidden_layers != 2, 4) (test/policy.jl:9-19).  The hidden->hidden block becomes a loop over
+// a.nl2 layers: the output tiles of every layer but the last are parked in a wave-private LDS region (lane-linear 1 KiB
+// rows, no barrier: only the wave itself reads them back) and re-loaded as the next layer's B operands; the last one feeds
+// the layer-3 dot epilogue as before (nl2 == 0: the dot runs on the layer-1 tiles).  Every layer walks its contraction in
+// the same accumulator-register order as layer 2, so the fp32 chain order per layer is the one the oracle's device-order
+// mode mirrors.  DEEP = 0 is the num_hidden_layers == 2 kernel, unchanged.  MODE 3 (persistent rollout) has no deep form:
+// its env slots and the park would share the LDS; deep policies roll out with the per-step launches.
+template <int F, int HID, int MODE, int TPS, int DEEP = 0>
 __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdArgs a) {
     constexpr int NT = HID / 32;       // 32-feature tiles
     constexpr int S41 = F / 8;         // float4 groups of layer-1 k-steps
@@ -90,9 +97,12 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
     // workgroup so the per-tile epilogues see an LDS round trip instead of a global (L1/L2) one
     __shared__ __attribute__((aligned(16))) float4 sW3[2 * NT * 16];     // [half][tile][reg]  (HID*4 floats)
     __shared__ __attribute__((aligned(16))) float4 sB1[NT * 2 * 4];      // [tile][half][4]    (HID floats)
-    __shared__ __attribute__((aligned(16))) float4 sB2[NT * 2 * 4];
+    constexpr int NB2L = DEEP ? 3 : 1;                                   // bias packs of up to three hidden->hidden layers
+    __shared__ __attribute__((aligned(16))) float4 sB2[NB2L * NT * 2 * 4];
+    static_assert(!(DEEP && MODE == 3), "no deep persistent rollout");
     for (int i = threadIdx.x; i < 2 * NT * 16; i += 256) sW3[i] = a.w3p[i];
-    for (int i = threadIdx.x; i < NT * 8; i += 256) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    for (int i = threadIdx.x; i < NT * 8; i += 256) sB1[i] = a.b1p[i];
+    for (int i = threadIdx.x; i < NT * 8 * (DEEP ? a.nl2 : 1); i += 256) sB2[i] = a.b2p[i];
     __syncthreads();
 
     // the rows of the NEXT 32-row tile are fetched while the current one computes (the gather through idx is two
@@ -275,7 +285,83 @@ __global__ __launch_bounds__(256, (FwdCfg<F, HID>::WPS)) void k_policy_fwd(FwdAr
             FSTAMP(1);
             // ---- layer 2 (MFMA, B operands = layer-1 accumulators) + layer 3 (VALU dot epilogue)
             float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-            {
+            if constexpr (DEEP) {
+                constexpr int S42 = NT * 4;
+                static_assert(S42 % PF == 0, "ring depth must divide the groups per tile");
+                // this wave's park: [NT tiles][4 quarter-tiles][64 lanes] float4
+                float4* const park = reinterpret_cast<float4*>(env_lds + a.park_off) + (size_t)(threadIdx.x >> 6) * NT * 256 + lane;
+                const int nl2 = a.nl2;
+                auto dot3 = [&](int o, const f32x16& acc) {
+                    const float4* w3 = sW3 + (half_o * NT + o) * 16;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 w = w3[r];
+                        p0 = fmaf(w.x, acc[r], p0); p1 = fmaf(w.y, acc[r], p1);
+                        p2 = fmaf(w.z, acc[r], p2); p3 = fmaf(w.w, acc[r], p3);
+                    }
+                };
+#pragma unroll 1
+                for (int l = 0; l < nl2; ++l) {
+                    const bool last = (l + 1 == nl2);                   // wave-uniform
+                    const float4* wp = a.w2p + (size_t)l * (HID * HID / 4) + lane_o;
+                    float4* const act_out = last ? a.act2 : a.act_mid[l < 2 ? l : 0];
+                    float4 ring[PF];
+#pragma unroll
+                    for (int g = 0; g < PF; ++g) ring[g] = wp[(size_t)g * 64];
+#pragma unroll 1
+                    for (int o = 0; o < NT; ++o) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 b = sB2[((l * NT + o) * 2 + half_o) * 4 + q];
+                            acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                        }
+                        const float4* wo = wp + (size_t)o * S42 * 64;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const int s4 = t * 4 + r4;
+                                const float4 w = ring[s4 % PF];
+                                ring[s4 % PF] = wo[(size_t)(s4 + PF) * 64];      // the next layer's head / the tail padding
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, h1[t][4 * r4 + 0], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, h1[t][4 * r4 + 1], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, h1[t][4 * r4 + 2], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, h1[t][4 * r4 + 3], acc, 0, 0, 0);
+                            }
+                        }
+                        asm volatile("" : "+v"(acc));
+                        lrelu16(acc);
+                        if (TRAIN && PPO_FWD_STORE) {
+                            float4* dst = act_out + ((size_t)tile * NT + o) * 4 * 64;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                ACT_STORE(dst + q * 64 + lane, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+                        }
+                        if (last) dot3(o, acc);
+                        else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                park[(o * 4 + q) * 64] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        }
+                    }
+                    if (!last) {                                        // this layer's output becomes the next layer's input
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: program order + in-order LDS suffice
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 v = park[(t * 4 + q) * 64];
+                                h1[t][4 * q + 0] = v.x; h1[t][4 * q + 1] = v.y; h1[t][4 * q + 2] = v.z; h1[t][4 * q + 3] = v.w;
+                            }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read back before the next layer overwrites the park
+                    }
+                }
+                if (nl2 == 0) {                                         // num_hidden_layers == 1: layer 3 on the layer-1 tiles
+#pragma unroll
+                    for (int o = 0; o < NT; ++o) dot3(o, h1[o]);
+                }
+            } else {
                 constexpr int S42 = NT * 4;                  // groups per output tile
                 static_assert(S42 % PF == 0, "ring depth must divide the groups per tile");
                 const float4* wp = a.w2p + lane_o;
@@ -408,8 +494,48 @@ __global__ void k_categorical(const float* __restrict__ probs, const float* __re
     err[b] = !(p[i] > 0.0f);
 }
 
+// num_hidden_layers != 2: the layer-looped instantiations (DEEP = 1).  Dynamic LDS = [MODE 4: one env-snapshot slot per
+// wave][park: 4 waves x HID/32 tiles x 4 KiB].
+template <int MODE>
+static int32_t dispatch_fwd_deep(ppo_policy_s* p, const FwdArgs& args, int64_t B, int tps) {
+    const int64_t need = (B + 3) / 4;
+    FwdArgs a = args;
+    a.nl2 = p->L - 1;
+    const size_t snap = (MODE == 4) ? (((size_t)4 * (2 * a.envV + 32) + 15) & ~(size_t)15) : 0;
+    a.park_off = (uint32_t)snap;
+#define LAUNCHD(FF, HH, TT)                                                                              \
+    do {                                                                                                 \
+        const int64_t cap = 256 * FwdCfg<FF, HH>::WPS;                                                   \
+        const unsigned grid = (unsigned)(need < cap ? need : cap);                                       \
+        a.wg_sync = 0;                                                                                   \
+        if constexpr (MODE == 4 && FF != 72) {                                                           \
+            ppo_set_error("compact rollouts need the built-in env's F = 72"); return PPO_ERR_UNSUPPORTED; \
+        } else {                                                                                         \
+            const size_t dlds = snap + (size_t)4 * (HH / 32) * 4096;                                     \
+            static size_t attr_lds = 0;                                                                  \
+            if (dlds > attr_lds) {                                                                       \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd<FF, HH, MODE, TT, 1>,              \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));     \
+                attr_lds = dlds;                                                                         \
+            }                                                                                            \
+            hipLaunchKernelGGL((k_policy_fwd<FF, HH, MODE, TT, 1>), dim3(grid), dim3(256), dlds, ppo_stream(), a); \
+        }                                                                                                \
+    } while (0)
+    if (p->F == 72 && p->HID == 256 && tps == 1) LAUNCHD(72, 256, 1);
+    else if (p->F == 72 && p->HID == 256 && tps == 4) LAUNCHD(72, 256, 4);
+    else if (p->F == 72 && p->HID == 128 && tps == 1) LAUNCHD(72, 128, 1);
+    else if (p->F == 72 && p->HID == 128 && tps == 4) LAUNCHD(72, 128, 4);
+    else if (p->F == 216 && p->HID == 128 && tps == 1) LAUNCHD(216, 128, 1);
+    else if (p->F == 216 && p->HID == 256 && tps == 1) LAUNCHD(216, 256, 1);
+    else { ppo_set_error("unsupported policy/state shape (F,HID,H) for the gfx950 kernels"); return PPO_ERR_UNSUPPORTED; }
+#undef LAUNCHD
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
+
 template <int MODE>
 static int32_t dispatch_fwd(ppo_policy_s* p, const FwdArgs& args, int64_t B, int tps) {
+    if (p->L != 2) return dispatch_fwd_deep<MODE>(p, args, B, tps);
     const int64_t need = (B + 3) / 4;
     // persistent waves: 256 CUs x WPS blocks of 4 waves (one per SIMD)
 #define LAUNCH(FF, HH, TT)                                                                               \
@@ -429,6 +555,7 @@ static int32_t dispatch_fwd(ppo_policy_s* p, const FwdArgs& args, int64_t B, int
     else if (p->F == 72 && p->HID == 128 && tps == 1) LAUNCH(72, 128, 1);
     else if (p->F == 72 && p->HID == 128 && tps == 4) LAUNCH(72, 128, 4);
     else if (p->F == 216 && p->HID == 128 && tps == 1) LAUNCH(216, 128, 1);
+    else if (p->F == 216 && p->HID == 256 && tps == 1) LAUNCH(216, 256, 1);
     else { ppo_set_error("unsupported policy/state shape (F,HID,H) for the gfx950 kernels"); return PPO_ERR_UNSUPPORTED; }
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
@@ -490,7 +617,7 @@ int32_t launch_policy_rollout(ppo_policy_s* p, ppo_env_s* e, const int8_t* state
 // t0: first row of the rollout columns this launch writes (streaming collects a long rollout as a chain of launches)
 int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_rollouts_s* ro, int64_t T, int record_probs,
                                          int64_t t0) {
-    if (p->F != 72 || e->F != 72) return PPO_ERR_UNSUPPORTED;
+    if (p->F != 72 || e->F != 72 || p->L != 2) return PPO_ERR_UNSUPPORTED;
     const int tps = e->H / 32;
     const int64_t N = e->N;
     const int64_t need = (N + 3) / 4;
@@ -551,6 +678,8 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
     fill_weights(p, a);
     a.states = ro->states.p; a.active = ro->active.p; a.idx = idx_dev; a.B = B;
     a.act1 = (float4*)p->act1.p; a.act2 = (float4*)p->act2.p; a.dY = (float4*)p->dY.p; a.loss_terms = p->loss_terms.p;
+    for (int l = 0; l < 2; ++l)          // deep policies: the hidden layers between the first and the last
+        a.act_mid[l] = (p->L > 2 && l < p->L - 2) ? (float4*)p->actm.p + (size_t)l * p->cap_tiles * (p->HID / 32) * 256 : nullptr;
     a.actions = ro->actions.p; a.p_old = ro->p_sel.p; a.adv = adv_col;
     a.eps = eps; a.c_over_B = (float)(entropy_weight / (double)B_global); a.inv_B = (float)(1.0 / (double)B_global);
     ProfScope ps("k_policy_fwd_train");

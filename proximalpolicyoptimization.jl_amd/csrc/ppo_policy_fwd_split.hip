@@ -222,7 +222,7 @@ static int32_t launch_split(FwdArgs& a, int64_t B) {
 
 // `a` comes filled like MODE 2 / MODE 4 of k_policy_fwd.  PPO_ERR_UNSUPPORTED (no error text): shape not covered.
 int32_t launch_policy_train_fwd_split(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
-    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || tps != 1) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || tps != 1 || p->L != 2) return PPO_ERR_UNSUPPORTED;
     if (p->HID == 256) return compact ? launch_split<72, 256, 1>(a, B) : launch_split<72, 256, 0>(a, B);
     if (p->HID == 128) return compact ? launch_split<72, 128, 1>(a, B) : launch_split<72, 128, 0>(a, B);
     return PPO_ERR_UNSUPPORTED;

@@ -267,7 +267,7 @@ static int32_t launch_rs(FwdArgs& a, int64_t N, int V) {
 // `a` comes filled from launch_policy_rollout_persistent (env = 1) or launch_policy_rollout (env = 0, one step).
 // PPO_ERR_UNSUPPORTED (no error text): shape not covered.
 int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V, int env) {
-    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || tps != 1 || V != 32) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || p->F != 72 || tps != 1 || V != 32 || p->L != 2) return PPO_ERR_UNSUPPORTED;
     if (p->HID == 256) return env ? launch_rs<256, 1>(a, N, V) : launch_rs<256, 0>(a, N, V);
     if (p->HID == 128) return env ? launch_rs<128, 1>(a, N, V) : launch_rs<128, 0>(a, N, V);
     return PPO_ERR_UNSUPPORTED;

@@ -38,6 +38,10 @@ struct FwdArgs {
     // [H][F] observation.  MODE 3 writes cstate_out (states_out may then be null); MODE 4 = MODE 2 (train forward) reading
     // cstate through idx, re-deriving the rows like MODE 3 and leaving them in xs_out (minibatch order) for the backward
     int8_t* cstate_out; const int8_t* cstate; int8_t* xs_out;
+    // deep form (num_hidden_layers != 2, k_policy_fwd<.., DEEP = 1>): nl2 = hidden->hidden layers (L - 1: 0, 2 or 3), w2p /
+    // b2p hold them back to back; act_mid[l] = saved output of hidden->hidden layer l < nl2 - 1 (the last one goes to act2,
+    // with nl2 == 0 only act1 exists); park_off = byte offset of the waves' activation park in dynamic LDS
+    int32_t nl2; float4* act_mid[2]; uint32_t park_off;
     // bf16 compute mode (ppo_policy_bf16.hip): bf16 fragment streams and bf16 saved activations
     const uint4* w1b; const uint4* w2b; const uint4* w3c; uint4* act1b; uint4* act2b;
 };
