@@ -402,7 +402,7 @@ def main():
             tf = flops_per_state("bwd") * MINIBATCH / (pair_ms * 1e-3) / 1e12
             kernels["k_policy_bwd+k_policy_dw1"] = {"avg_ms": round(pair_ms, 4), "launches": kernels["k_policy_bwd"]["launches"],
                                                     "tflops": round(tf, 2), "frac": round(tf / peak, 4)}
-        for name in ("k_policy_bwd_data", "k_policy_wgrad", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
+        for name in ("k_policy_train_tile", "k_policy_bwd_data", "k_policy_wgrad", "k_returns_tn", "k_env_step", "k_env_observe", "k_grad_reduce", "k_adam",
                      "k_reduce_adam", "allreduce"):
             ms, n = PPO.profile_get(name)
             if n:

@@ -18,8 +18,8 @@
  *    F = 72 features: 36 template scores then 36 template degrees); the action mask travels as
  *    the active-quad bit mask (bit q set = quad q active; entries a with quad a/16 inactive are
  *    -Inf in the reference, test/quad_game_utilities.jl:39-44).
- *  - policy parameters are one flat float32 vector in Flux order (W1,b1,W2,b2,W3,b3), W stored
- *    [out,in] column-major, so Flux.params(policy) round-trips (test/policy.jl:9-19).
+ *  - policy parameters are one flat float32 vector in Flux order (W1,b1, the num_hidden_layers-1 hidden->hidden
+ *    (W,b) pairs, W_out,b_out), W stored [out,in] column-major, so Flux.params(policy) round-trips (test/policy.jl:9-19).
  *  - not re-entrant per handle; one host thread and one HIP stream per process (ppo_set_stream).
  */
 #ifndef PPO_HIP_H
@@ -118,7 +118,10 @@ int32_t ppo_env_check_errors(ppo_env_t env, int32_t* flags_or_null);
 int32_t ppo_env_set_strict_sampling(ppo_env_t env, int32_t strict);
 
 /* ---------------------------------------------------------------- policy plugin */
-/* SimplePolicy.Policy(in, hidden, num_hidden_layers, out)  test/policy.jl:9-19 */
+/* SimplePolicy.Policy(in, hidden, num_hidden_layers, out)  test/policy.jl:9-19
+ * in = 72 or 216 features, hidden = 1..256 (widths other than 128 / 256 run zero-padded on the next wider kernel, exact),
+ * num_hidden_layers = 1..4 (2: the fused kernels; 1, 3, 4: the layer-looped forms of the same kernels, fp32 only),
+ * out = 4 (the quad game's actions per edge, test/quad_game_utilities.jl:95).  Anything else: PPO_ERR_UNSUPPORTED. */
 int32_t ppo_policy_create(int32_t F, int32_t hidden, int32_t num_hidden_layers,
                           int32_t out_per_edge, ppo_policy_t* out);
 /* arithmetic type of the policy MLP (BASELINE config 5: "bf16 MLP on MFMA + fp32 GAE").  PPO_DTYPE_F32 (default):
@@ -162,6 +165,10 @@ int32_t ppo_adam_set_epoch_count(ppo_adam_t opt, int64_t epochs);
 /* ---------------------------------------------------------------- rollout buffer */
 /* BufferRollouts()                                          src/rollout_buffer.jl:1-22 */
 int32_t ppo_rollouts_create(ppo_env_t env, int64_t capacity_T, ppo_rollouts_t* out);
+/* the same for states that do not come from the built-in env (a user env's state(env) converted by the host, e.g. the
+ * reference's 216-feature level-4 template, test/output/catmull-clark-policy-l4.bson): N columns of [H][F] int8 rows,
+ * H = 32 or 128, F a multiple of 8 the policy was created for; filled with ppo_rollouts_set */
+int32_t ppo_rollouts_create_shape(int64_t num_envs, int32_t H, int32_t F, int64_t capacity_T, ppo_rollouts_t* out);
 int32_t ppo_rollouts_destroy(ppo_rollouts_t ro);
 int32_t ppo_rollouts_len(ppo_rollouts_t ro, int64_t* n);                 /* Base.length :40-48 */
 int32_t ppo_rollouts_dims(ppo_rollouts_t ro, int64_t* T, int64_t* N);
@@ -215,6 +222,12 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
  * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
  * keeps every weight gradient resident in MFMA accumulators.  Default 384 (-1 restores it), 0 = always fused. */
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
+/* Small minibatches (the per-GPU shard of a strong-scaling run): up to `tiles` 32-row tiles the train forward, the loss and
+ * the backward-data pass of a tile run in ONE workgroup (k_policy_train_tile: nothing but the operands of the weight-
+ * gradient products leaves the CU) followed by the split-K weight-gradient kernel, instead of the separate forward and
+ * backward launches.  Same gradient to fp32 rounding (the layer-3 partial sums are added in another order), bitwise
+ * reproducible.  -1 restores the default, 0 = never. */
+int32_t ppo_set_train_tile_max_tiles(int64_t tiles);
 /* Likewise for the train forward: minibatches of up to `states` states (H = 32) give every state to 2 or 4 waves instead
  * of one, so a minibatch smaller than the chip's 1024 SIMDs still fills it (logits agree with the one-wave kernel to
  * fp32 rounding: the layer-3 partial sums are added in a different order).  Default 512 (-1 restores it), 0 = never. */

@@ -111,6 +111,12 @@ def set_bwd_small_max_tiles(tiles=None):
     call("ppo_set_bwd_small_max_tiles", -1 if tiles is None else int(tiles))
 
 
+def set_train_tile_max_tiles(tiles=None):
+    """Minibatches of up to `tiles` 32-row tiles run forward + loss + backward-data of each tile in one workgroup
+    (k_policy_train_tile) followed by the split-K weight-gradient kernel.  None = default, 0 = never."""
+    call("ppo_set_train_tile_max_tiles", -1 if tiles is None else int(tiles))
+
+
 def set_fwd_split_max_states(states=None):
     """Minibatches of up to `states` states use the train forward that gives each state to 2 or 4 waves.  None = default
     (512), 0 = always one wave per state."""
@@ -521,6 +527,13 @@ def philox4x32_10(ctr, key):
 
 
 # ------------------------------------------------------------------ rollouts / dataset
+class _Shape:
+    """Stand-in for the env of a rollout buffer created by shape (N columns of [H][F] int8 state rows)."""
+
+    def __init__(self, N, H, F):
+        self.N, self.H, self.F, self.A = int(N), int(H), int(F), 4 * int(H)
+
+
 class BufferRollouts:
     """PPO.BufferRollouts() (src/rollout_buffer.jl:1-22): device-resident SoA columns [T,N]."""
 
@@ -532,7 +545,10 @@ class BufferRollouts:
     def _ensure(self, env, T):
         if self._h is None:
             h = C.c_void_p()
-            call("ppo_rollouts_create", env._h, int(T), C.byref(h))
+            if isinstance(env, _Shape):      # states of a user env (any F the policy kernels take): ppo_rollouts_create_shape
+                call("ppo_rollouts_create_shape", env.N, env.H, env.F, int(T), C.byref(h))
+            else:
+                call("ppo_rollouts_create", env._h, int(T), C.byref(h))
             self._h, self._env = h, env
         return self._h
 
@@ -613,9 +629,12 @@ class BufferRollouts:
         return idx
 
     def set_columns(self, env, states, active, actions1, p_sel, returns, terminal=None):
-        """Load columns from the host (generic host-side envs, tests)."""
+        """Load columns from the host (generic host-side envs, tests).  env = None: the buffer takes its shape from
+        `states` [T,N,H,F] (a user env whose state rows are not the built-in env's 72 features)."""
         st = np.ascontiguousarray(states, np.int8)
         T = st.shape[0]
+        if env is None:
+            env = _Shape(st.shape[1], st.shape[2], st.shape[3])
         self._ensure(env, T)
         ac = np.ascontiguousarray(active, np.uint32)
         a0 = np.ascontiguousarray(np.asarray(actions1, np.int64) - 1, np.int32)

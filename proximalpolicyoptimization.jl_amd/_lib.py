@@ -68,6 +68,7 @@ SIGNATURES = {
     "ppo_adam_get_epoch_count": [H, c_i64p],
     "ppo_adam_set_epoch_count": [H, C.c_int64],
     "ppo_rollouts_create": [H, C.c_int64, HP],
+    "ppo_rollouts_create_shape": [C.c_int64, C.c_int32, C.c_int32, C.c_int64, HP],
     "ppo_rollouts_destroy": [H],
     "ppo_rollouts_len": [H, c_i64p],
     "ppo_rollouts_dims": [H, c_i64p, c_i64p],
@@ -85,6 +86,7 @@ SIGNATURES = {
     "ppo_rollouts_set": [H, C.c_int64, c_i8p, c_u32p, c_i32p, c_f32p, c_f32p, c_u8p],
     "ppo_forward_backward": [H, H, c_i64p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32],
     "ppo_set_bwd_small_max_tiles": [C.c_int64],
+    "ppo_set_train_tile_max_tiles": [C.c_int64],
     "ppo_set_fwd_split_max_states": [C.c_int64],
     "ppo_set_rollout_split_max_envs": [C.c_int64],
     "ppo_adam_apply": [H, H],

@@ -302,6 +302,7 @@ int32_t ppo_set_rollout_persistent(int32_t mode) { g_rollout_persistent = mode <
 static int g_rollout_compact = [] { const char* v = std::getenv("PPO_ROLLOUT_COMPACT"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : -1; }();
 int32_t ppo_set_rollout_compact(int32_t mode) { g_rollout_compact = mode < 0 ? -1 : (mode != 0); return PPO_OK; }
 static bool want_compact(const ppo_rollouts_s* ro, int64_t T) {
+    if (ro->V == 0) return false;                             // created by shape: no env snapshot form
     if (g_rollout_compact >= 0) return g_rollout_compact == 1;
     if (ro->sink) return true;
     static const double limit = [] { const char* v = std::getenv("PPO_COMPACT_AUTO_BYTES"); return v ? atof(v) : 32.0 * 1024 * 1024 * 1024; }();
@@ -559,6 +560,20 @@ int32_t ppo_rollouts_create(ppo_env_t env, int64_t capacity_T, ppo_rollouts_t* o
     int32_t s = r->tmpl.alloc((size_t)env->H * PPO_TPL);
     if (!s && hipMemcpyAsync(r->tmpl.p, env->tmpl.p, (size_t)env->H * PPO_TPL, hipMemcpyDeviceToDevice, g_stream) != hipSuccess) s = PPO_ERR_HIP;
     if (!s) s = rollouts_reserve(r, capacity_T, want_compact(r, capacity_T));
+    if (s) { delete r; return s; }
+    *out = r;
+    return PPO_OK;
+}
+// BufferRollouts for states that do not come from the built-in env: any feature count the policy kernels take (F = 72 or
+// 216 int8 features per half-edge row), H = 32 or 128 rows.  Host-supplied columns only (ppo_rollouts_set): the
+// expanded storage form, no env template.
+int32_t ppo_rollouts_create_shape(int64_t num_envs, int32_t H, int32_t F, int64_t capacity_T, ppo_rollouts_t* out) {
+    PPO_TRY(ensure_init());
+    ARG_CHECK(out && num_envs >= 1 && capacity_T >= 0, "BufferRollouts: bad argument");
+    ARG_CHECK((H == 32 || H == 128) && F >= 8 && F % 8 == 0, "BufferRollouts: H must be 32 or 128 rows, F a multiple of 8");
+    ppo_rollouts_s* r = new ppo_rollouts_s();
+    r->N = num_envs; r->H = H; r->F = F; r->A = 4 * H; r->V = 0; r->capT = 0; r->T = 0; r->len = 0;
+    const int32_t s = rollouts_reserve(r, capacity_T, false);
     if (s) { delete r; return s; }
     *out = r;
     return PPO_OK;
@@ -897,6 +912,14 @@ static int64_t g_bwd_small_max_tiles = [] { const char* v = std::getenv("PPO_BWD
 
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles) { g_bwd_small_max_tiles = tiles < 0 ? 384 : tiles; return PPO_OK; }
 
+// minibatches up to this many tiles run forward + loss + backward-data of each tile in one workgroup (k_policy_train_tile)
+// and the weight gradients as a split-K product on operand-layout tiles.  PPO_TRAIN_TILE_MAX_TILES overrides (0 = never).
+#ifndef PPO_TRAIN_TILE_DEFAULT
+#define PPO_TRAIN_TILE_DEFAULT 0
+#endif
+static int64_t g_train_tile_max_tiles = [] { const char* v = std::getenv("PPO_TRAIN_TILE_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_TRAIN_TILE_DEFAULT; }();
+int32_t ppo_set_train_tile_max_tiles(int64_t tiles) { g_train_tile_max_tiles = tiles < 0 ? PPO_TRAIN_TILE_DEFAULT : tiles; return PPO_OK; }
+
 // ================================================================ training
 // B = number of 32-row tiles of the minibatch (states * H/32)
 static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
@@ -927,6 +950,18 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
         PPO_TRY(pol->adv_col.alloc((size_t)ro->capT * ro->N));
         PPO_TRY(launch_adv_normalise(adv, idx_dev, B, pol->adv_col.p));
         adv = pol->adv_col.p;
+    }
+    // small minibatches: the whole training pass of a tile on one CU (ppo_policy_train_tile.hip), then the weight gradients
+    if (B * (ro->H / 32) <= g_train_tile_max_tiles && pol->L == 2 && pol->dtype == PPO_DTYPE_F32) {
+        const size_t frag = (size_t)pol->cap_tiles * (pol->HID / 32) * 1024;
+        PPO_TRY(pol->dz1f.alloc(frag)); PPO_TRY(pol->dz2f.alloc(frag));
+        const int32_t ts = launch_policy_train_tile(pol, ro, idx_dev, B, B_global, eps, ew, adv);
+        if (ts != PPO_ERR_UNSUPPORTED) {
+            if (ts != PPO_OK) return ts;
+            PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
+            pol->last_B = B; pol->last_entropy_weight = ew;
+            return PPO_OK;
+        }
     }
     PPO_TRY(launch_policy_train_fwd(pol, ro, idx_dev, B, B_global, eps, ew, adv));
     // small minibatches: three-product backward (no per-workgroup gradient slabs); otherwise the fused kernel

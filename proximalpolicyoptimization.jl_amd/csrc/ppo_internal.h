@@ -226,6 +226,10 @@ int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 // three-product backward for small minibatches (ppo_policy_bwd_small.hip); PPO_ERR_UNSUPPORTED: not covered
 int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+// small minibatches: forward + loss + backward-data of a tile in one workgroup, then the weight-gradient kernel
+// (ppo_policy_train_tile.hip); PPO_ERR_UNSUPPORTED: not covered
+int32_t launch_policy_train_tile(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B, int64_t B_global,
+                                 double eps, double entropy_weight, const float* adv_col);
 // bf16 compute mode (ppo_policy_bf16.hip); MODE as in k_policy_fwd: 0 probs, 1 rollout, 2 train
 struct FwdArgs;
 // one-launch rollout with 2 or 4 waves per env for few envs, bit-identical results (ppo_policy_rollout_split.hip)

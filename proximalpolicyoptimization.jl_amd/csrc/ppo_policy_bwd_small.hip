@@ -18,6 +18,7 @@
 //   k_grad_reduce       unchanged: fixed-order sum of the virtual slabs -> flat Flux-order gradient (bitwise reproducible)
 #include "ppo_internal.h"
 #include "ppo_device.h"
+#include <cstdlib>
 
 #define SB_LD 36        // LDS leading dimension (rows) of the transposed tiles: see k_policy_bwd
 
@@ -430,7 +431,10 @@ __device__ __forceinline__ void frag_to_lds(float* buf, const float4 (&v)[4], in
     }
 }
 
-template <int F, int HID>
+// TR = 1: dzl[] / actl[] hold the tiles in the OPERAND LAYOUT of the row contraction (lane = feature, element q of the
+// tile = rows 16 * half + 4q .. + 3: what k_policy_train_tile stores) -- the A / B operands are plain wave loads and no
+// LDS transposes are left in this kernel; TR = 0: fragment order (lane = row), transposed through wave-private LDS tiles.
+template <int F, int HID, bool TR>
 __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
     constexpr int NT = HID / 32, LD = SB_LD, FP = ((F + 31) / 32) * 32, NI = FP / 32;
     constexpr int NB2 = (NT / 2) * (NT / 2);            // 64 x 64 blocks of dW2 (2 A tiles + 2 B tiles)
@@ -483,6 +487,26 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
         };
         if (t0 + v < t1) fetch(t0 + v);
         for (int64_t t = t0 + v; t < t1; t += 4) {
+            if constexpr (TR) {
+                float4 ca[2][4], cb[2][4];                             // element q of a tile IS the operand of k-steps 4q .. 4q+3
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ca[x][q] = fa[x][q]; cb[x][q] = fbv[x][q]; }
+                if (t + 4 < t1) fetch(t + 4);                          // next row tile lands under the MFMAs
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) {
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[x][q].x, cb[y][q].x, acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[x][q].y, cb[y][q].y, acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[x][q].z, cb[y][q].z, acc[x][y], 0, 0, 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[x][q].w, cb[y][q].w, acc[x][y], 0, 0, 0);
+                        }
+                continue;
+            }
 #pragma unroll
             for (int x = 0; x < 2; ++x) { frag_to_lds(bufA + x * TILE, fa[x], j, h); frag_to_lds(bufB + x * TILE, fbv[x], j, h); }
             if (t + 4 < t1) fetch(t + 4);                              // next row tile lands under the MFMAs
@@ -544,7 +568,11 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
         };
         if (t0 + v < t1) fetch(t0 + v);
         for (int64_t t = t0 + v; t < t1; t += 4) {
-            frag_to_lds(bufA, fa, j, h);
+            float4 ca[4];
+            if constexpr (TR) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ca[q] = fa[q];
+            } else frag_to_lds(bufA, fa, j, h);
 #pragma unroll
             for (int i = 0; i < XPL; ++i) {
                 const int d = lane + 64 * i;                          // dword d = row * (F/4) + c: features 4c .. 4c+3
@@ -556,9 +584,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
             }
             if (t + 4 < t1) fetch(t + 4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const float4 a4 = *reinterpret_cast<const float4*>(bufA + j * LD + 16 * h + 4 * q);
+            auto dw1_step = [&](const float4 a4, const int q) {
                 float4 b4[NI];
 #pragma unroll
                 for (int y = 0; y < NI; ++y) b4[y] = *reinterpret_cast<const float4*>(bufB + y * TILE + j * LD + 16 * h + 4 * q);
@@ -569,6 +595,13 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
                     acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[y].z, acc[y], 0, 0, 0);
                     acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[y].w, acc[y], 0, 0, 0);
                 }
+            };
+            if constexpr (TR) {                                        // static register indices: a dynamic q would put ca[] in scratch
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dw1_step(ca[q], q);
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) dw1_step(*reinterpret_cast<const float4*>(bufA + j * LD + 16 * h + 4 * q), q);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -587,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
 }
 
 template <int F, int HID>
-static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
+static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a, int tr_tail_wg = 0) {
     constexpr int NT = HID / 32, NI = (F + 31) / 32, WT = (1 + NI > 4) ? 1 + NI : 4;
     const size_t z2 = PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * SB_LD;
     const size_t lds_data = sizeof(float) * (z2 + (size_t)2 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
@@ -597,10 +630,12 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_data));
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data_deep<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_deep));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_wgrad<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_wgrad<F, HID, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_policy_wgrad<F, HID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
         attr_set = true;
     }
-    const int nwg = (int)(a.B < 256 ? a.B : 256);
+    static const int dbg_cap = [] { const char* v = getenv("PPO_DEBUG_BWD_DATA_WGS"); return v ? atoi(v) : 256; }();
+    const int nwg = (int)(a.B < dbg_cap ? a.B : dbg_cap);
     const int blocks = (a.L - 1) * (NT / 2) * (NT / 2) + NT;
     // K-slices: two workgroups per CU over the block list, all resident at once (a partial second round costs a whole one)
     int ks = 512 / blocks;
@@ -609,6 +644,13 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     a.ksplit = ks;
     p->nwg_bwd = ks;                 // slabs holding weight-gradient partials (one per K-slice)
     p->nwg_small = nwg;              // slabs holding the small-gradient tails
+    if (tr_tail_wg > 0) {            // the dZ / H1 tiles come from k_policy_train_tile, in operand layout: weight gradients only
+        p->nwg_small = tr_tail_wg;
+        ProfScope ps("k_policy_wgrad");
+        hipLaunchKernelGGL((k_policy_wgrad<F, HID, true>), dim3(blocks * ks), dim3(256), lds_w, ppo_stream(), a);
+        HIP_TRY(hipGetLastError());
+        return PPO_OK;
+    }
     {
         ProfScope ps("k_policy_bwd_data");
         if (a.L == 2) hipLaunchKernelGGL((k_policy_bwd_data<F, HID>), dim3(nwg), dim3(HID * 2), lds_data, ppo_stream(), a);
@@ -616,14 +658,25 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a) {
     }
     {
         ProfScope ps("k_policy_wgrad");
-        hipLaunchKernelGGL((k_policy_wgrad<F, HID>), dim3(blocks * ks), dim3(256), lds_w, ppo_stream(), a);
+        hipLaunchKernelGGL((k_policy_wgrad<F, HID, false>), dim3(blocks * ks), dim3(256), lds_w, ppo_stream(), a);
     }
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }
 
+static int32_t bwd_small_impl(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B, int tr_tail_wg);
+
 // PPO_ERR_UNSUPPORTED (no error text): shape or size not covered -> the caller runs the fused kernel
 int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
+    return bwd_small_impl(p, ro, idx_dev, B, 0);
+}
+// weight gradients from the operand-layout tiles k_policy_train_tile left in act1 / dz2f / dz1f; nwg_tail = its workgroups
+// (the slabs holding the small-gradient tails)
+int32_t launch_policy_wgrad_tr(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B, int nwg_tail) {
+    return bwd_small_impl(p, ro, idx_dev, B, nwg_tail);
+}
+
+static int32_t bwd_small_impl(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B, int tr_tail_wg) {
     if (p->dtype != PPO_DTYPE_F32 || !p->dz1f.p || (p->L >= 2 && !p->dz2f.p) || (p->L > 2 && !p->dzm.p)) return PPO_ERR_UNSUPPORTED;
     BwdSmallArgs a;
     a.tps = ro->H / 32;
@@ -642,8 +695,9 @@ int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
         a.actl[l] = first ? (const float4*)p->act1.p : (last ? (const float4*)p->act2.p : (const float4*)p->actm.p + (size_t)(l - 1) * lstride);
         a.dzl[l] = first ? (float4*)p->dz1f.p : (last ? (float4*)p->dz2f.p : (float4*)p->dzm.p + (size_t)(l - 1) * lstride);
     }
-    if (p->F == 72 && p->HID == 256) return launch_small<72, 256>(p, a);
-    if (p->F == 72 && p->HID == 128) return launch_small<72, 128>(p, a);
+    if (p->F == 72 && p->HID == 256) return launch_small<72, 256>(p, a, tr_tail_wg);
+    if (p->F == 72 && p->HID == 128) return launch_small<72, 128>(p, a, tr_tail_wg);
+    if (tr_tail_wg) return PPO_ERR_UNSUPPORTED;
     if (p->F == 216 && p->HID == 256) return launch_small<216, 256>(p, a);
     if (p->F == 216 && p->HID == 128) return launch_small<216, 128>(p, a);
     return PPO_ERR_UNSUPPORTED;

@@ -95,11 +95,13 @@ struct TailPre { int ab; float po; float adv; };
 // MODE 2 also serves the train forward from compact states (kernel MODE 4).
 // MODE 1 / 3 (rollout): tick_val = the env's tick (Philox counter word), out_index = position of the transition in
 // the output columns (state for one step, t*N + state for the persistent rollout); returns the sampled action.
+// dy_copy (MODE 2, TPS == 1, optional): a second destination for the state's 32 dL/dlogits rows, e.g. an LDS tile of the
+// calling workgroup (k_policy_train_tile keeps the whole training pass of a tile on the CU).
 template <int MODE, int TPS, bool DYBF16>
 __device__ __forceinline__ int policy_tail(const FwdArgs& a, const int64_t state, const int64_t sid, const uint32_t act,
                                            float (&l)[TPS][4], const int lane, const int j, const int h,
                                            const uint32_t tick_val = 0u, const int64_t out_index = 0,
-                                           const TailPre* pre = nullptr) {
+                                           const TailPre* pre = nullptr, float4* dy_copy = nullptr) {
     int sampled = 0;
     constexpr int A = 128 * TPS;
     // ---- masked softmax over the A = 128*TPS logits of the state (quad of row 32ts+j = 8ts + j/4)
@@ -224,10 +226,13 @@ __device__ __forceinline__ int policy_tail(const FwdArgs& a, const int64_t state
         dot = wave32_sum(dot);
         if (h == 0) {
 #pragma unroll
-            for (int ts = 0; ts < TPS; ++ts)
-                a.dY[((size_t)state * TPS + ts) * 32 + j] =
+            for (int ts = 0; ts < TPS; ++ts) {
+                const float4 dyv =
                     make_float4(dy_round<DYBF16>(p[ts][0] * (dp[ts][0] - dot)), dy_round<DYBF16>(p[ts][1] * (dp[ts][1] - dot)),
                                 dy_round<DYBF16>(p[ts][2] * (dp[ts][2] - dot)), dy_round<DYBF16>(p[ts][3] * (dp[ts][3] - dot)));
+                a.dY[((size_t)state * TPS + ts) * 32 + j] = dyv;
+                if (TPS == 1 && dy_copy) dy_copy[j] = dyv;
+            }
         }
         if (lane == 0) { a.loss_terms[state * 2] = minval; a.loss_terms[state * 2 + 1] = (double)(-hl); }
     }

@@ -10,6 +10,7 @@
 // Roofline: HBM-bound, 9 B per transition (r f32 + done u8 in, return f32 out).
 #include "ppo_internal.h"
 #include "ppo_device.h"
+#include <cstdlib>
 
 #define RT_CH 32          // rows per wave per pass
 #define RT_WAVES 4
@@ -309,19 +310,28 @@ int32_t launch_returns_tn(const float* r, const uint8_t* done, float* out, int64
     if (T <= 0 || N <= 0) return PPO_OK;
     ProfScope ps("k_returns_tn");
     if (N % 4 == 0 && N >= 16384) {                  // wide columns: 1 KiB per wave access
-        // (a single-pass variant -- one [128][128] tile, every load of the workgroup in flight at once -- was measured
-        // slower: 22.4 vs 19.2 us at 65536 x 128; the 128-step scan then cannot overlap with the loads)
-        const int cols = (N / 256 >= 1024) ? 256 : 128;      // keep >= 2 workgroups per CU below 262144 columns
-        dim3 gridw((unsigned)((N + cols - 1) / cols));
-        if (cols == 256) {
-            if (f32mode) hipLaunchKernelGGL((k_returns_tn_x4<1, 256, 32, 2>), gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
-            else hipLaunchKernelGGL((k_returns_tn_x4<0, 256, 32, 2>), gridw, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);
-        } else {
-            if (f32mode) hipLaunchKernelGGL((k_returns_tn_x4<1, 128, 32, 2>), gridw, dim3(128), 0, ppo_stream(), r, done, out, T, N, discount);
-            else hipLaunchKernelGGL((k_returns_tn_x4<0, 128, 32, 2>), gridw, dim3(128), 0, ppo_stream(), r, done, out, T, N, discount);
-        }
-        HIP_TRY(hipGetLastError());
-        return PPO_OK;
+        // Tile shape by column count, from an A/B of the shapes on one box (PPO_RETURNS_VARIANT, tools/returns_ab.py,
+        // gpurun_out/r3d; us at 16384 / 65536 / 262144 columns x 128 rows):
+        //   128 cols x 32 rows (round 2)  13.8 / 19.1 / 61.3      64 x 16   14.9 / 17.8 / 57.6
+        //   128 x 16                      14.9 / 18.7 / 50.8     256 x 16   15.9 / 17.7 / 52.5
+        //   128 x 8                       16.4 / 19.6 / 51.2      64 x 8    15.5 / 18.3 / 55.8     256 x 32  16.2 / 20.2 / 61.6
+        // 16-row passes beat 32-row ones once the launch is more than one round of workgroups (20 KB of LDS: eight
+        // workgroups per CU, finer interleaving of load / scan / store phases); measured and dropped: a single 128-row
+        // pass (22.4 us at 65536), two passes of load lookahead instead of one (+1 us at every size: the second register
+        // set costs more in the scan loop than the deeper queue gains -- the workgroups of a CU already overlap each other).
+        static const int variant = [] { const char* v = getenv("PPO_RETURNS_VARIANT"); return v ? atoi(v) : 0; }();
+#define RV(C, R) { dim3 g((unsigned)((N + (C) - 1) / (C)));                                                                  \
+            if (f32mode) hipLaunchKernelGGL((k_returns_tn_x4<1, C, R, 2>), g, dim3(C), 0, ppo_stream(), r, done, out, T, N, discount); \
+            else hipLaunchKernelGGL((k_returns_tn_x4<0, C, R, 2>), g, dim3(C), 0, ppo_stream(), r, done, out, T, N, discount); \
+            HIP_TRY(hipGetLastError()); return PPO_OK; }
+        if (variant == 12832) RV(128, 32)
+        if (variant == 12816) RV(128, 16)
+        if (variant == 6416) RV(64, 16)
+        if (variant == 25616) RV(256, 16)
+        if (N >= 131072) RV(128, 16)
+        if (N >= 32768) RV(64, 16)
+        RV(128, 32)
+#undef RV
     }
     dim3 grid((unsigned)((N + RT_COLS - 1) / RT_COLS));
     if (f32mode) hipLaunchKernelGGL(k_returns_tn<1>, grid, dim3(256), 0, ppo_stream(), r, done, out, T, N, discount);

@@ -311,7 +311,9 @@ def test_policy_any_hidden_width(P, orc, hid):
     with pytest.raises(P.PPOError):
         P.HipPolicy(72, 300, 2, 4)
     with pytest.raises(P.PPOError):
-        P.HipPolicy(72, 128, 3, 4)
+        P.HipPolicy(72, 128, 5, 4)             # num_hidden_layers 1..4 (tests/test_gpu_deep_policy.py)
+    with pytest.raises(P.PPOError):
+        P.HipPolicy(72, 128, 2, 5)             # the quad game has 4 actions per edge
 
 
 # ---------------------------------------------------------------- rollout (K1-K6 end to end)
@@ -375,16 +377,22 @@ def storage_mode(request, P):
     P.set_rollout_compact(None)
 
 
-@pytest.fixture(params=[0, 4096], ids=["large-batch-kernels", "small-batch-kernels"])
+@pytest.fixture(params=[0, 4096, -1], ids=["large-batch-kernels", "small-batch-kernels", "train-tile-kernels"])
 def bwd_form(request, P):
-    """Both kernel sets at test sizes: the fused backward + one-wave-per-state train forward (forced), and what small
-    minibatches take by default: the three-product backward and the 2 / 4-waves-per-state train forward
-    (ppo_set_bwd_small_max_tiles, ppo_set_fwd_split_max_states)."""
-    P.set_bwd_small_max_tiles(request.param)
-    P.set_fwd_split_max_states(min(request.param, 512))
+    """All three kernel sets at test sizes: the fused backward + one-wave-per-state train forward (forced); the three-product
+    backward and the 2 / 4-waves-per-state train forward (ppo_set_bwd_small_max_tiles, ppo_set_fwd_split_max_states); and
+    the one-workgroup-per-tile training pass + operand-layout weight-gradient kernel (ppo_set_train_tile_max_tiles; it
+    covers Q = 8 states in the expanded storage form and falls back to the others elsewhere)."""
+    if request.param < 0:
+        P.set_train_tile_max_tiles(1 << 20)
+    else:
+        P.set_train_tile_max_tiles(0)
+        P.set_bwd_small_max_tiles(request.param)
+        P.set_fwd_split_max_states(min(request.param, 512))
     yield request.param
     P.set_bwd_small_max_tiles(None)
     P.set_fwd_split_max_states(None)
+    P.set_train_tile_max_tiles(None)
 
 
 @pytest.mark.parametrize("case", range(10))
