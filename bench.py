@@ -33,15 +33,18 @@ QUADS = 8                             # quad slots per env: H = 4*QUADS half-edg
 GAMMA, EPS, ENT_W, LR = 1.0, 0.05, 0.01, 1e-4
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # same table, "Peak BF16/FP16 MFMA ~2.5 PF dense" (--dtype bf16 runs only)
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # tools/pmc_traffic.py: measured HBM bytes per launch, keyed by launch shape
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # tools/pmc_traffic2.py: measured HBM bytes per launch, keyed by launch shape
+LAYERS = 2                            # hidden layers of the policy (test/policy.jl:9-19); 2 = the headline 2x256 MLP
 
 
 def flops_per_state(kind):
     """Algorithmic flops of one 32-row state tile on the matrix pipe (DESIGN.md 'Kernels')."""
     rows = 4 * QUADS                     # half-edge rows of one state (32 for the headline workload)
-    fwd = 2 * rows * (F * HID + HID * HID + HID * 4)
+    fwd = 2 * rows * (F * HID + (LAYERS - 1) * HID * HID + HID * 4)
     if kind == "fwd":
         return fwd
+    if LAYERS != 2:                      # deep policies: dH and dW of every hidden->hidden layer, dW1, dW3 / dH_top
+        return 2 * rows * (2 * (LAYERS - 1) * HID * HID + HID * F + 2 * HID * 4)
     # backward: dH1 = W2^T dZ2 (HID*HID), dW2 (HID*HID), dW1 (HID*F), dW3/dH2 (2*HID*4)
     if kind == "bwd_no_dw1":             # bf16 mode at HID = 256: dW1 = dZ1 X^T runs in k_policy_dw1_bf16, not in k_policy_bwd_bf16
         return 2 * rows * (2 * HID * HID + 2 * HID * 4)
@@ -246,7 +249,7 @@ def launch_ranks(n):
 
 
 def main():
-    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS, HID
+    global T_STEPS, EPOCHS, N_ENVS, MINIBATCH, QUADS, HID, LAYERS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -263,6 +266,8 @@ def main():
                          "file; BASELINE config 5 'rollouts streamed to disk'); training reads the resident copy.  Not the headline")
     ap.add_argument("--hid", type=int, choices=[128, 256], default=HID,
                     help="hidden width: 256 = the headline 2x256 MLP, 128 = the reference's own Policy(72,128,2,4) (not the headline)")
+    ap.add_argument("--layers", type=int, choices=[1, 2, 3, 4], default=LAYERS,
+                    help="hidden layers of the policy: 2 = the headline MLP; 1, 3, 4 run the layer-looped kernels (not the headline)")
     ap.add_argument("--quads", type=int, choices=[8, 32], default=QUADS,
                     help="quad slots per env: 8 = the headline rand-poly shape (A=128), 32 = the square-mesh-sized action "
                          "space of BASELINE config 4 (A=512, variable-length masked episodes; flagged in the output)")
@@ -272,8 +277,9 @@ def main():
     args = ap.parse_args()
     reduced = (args.t_steps != T_STEPS) or (args.epochs != EPOCHS)
     T_STEPS, EPOCHS = args.t_steps, args.epochs
-    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS) or (args.hid != HID) or bool(args.stream)
+    nonheadline = (args.dtype != "f32") or (args.envs != N_ENVS) or (args.scaling != "weak") or (args.quads != QUADS) or (args.hid != HID) or bool(args.stream) or (args.layers != LAYERS)
     HID = args.hid
+    LAYERS = args.layers
     QUADS = args.quads
     N_ENVS = MINIBATCH = args.envs
 
@@ -328,7 +334,7 @@ def main():
         PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     dp = PPO.DataParallel(rank, world, force_hook=use_dist)
-    pol = PPO.HipPolicy(F, HID, 2, 4, seed=0, dtype=args.dtype)
+    pol = PPO.HipPolicy(F, HID, LAYERS, 4, seed=0, dtype=args.dtype)
     opt = PPO.Optimiser(PPO.Adam(LR))
 
     def sync():
@@ -397,6 +403,12 @@ def main():
                 tf = flops_per_state(kind) * per / (avg * 1e-3) / 1e12
                 kernels[name] = {"avg_ms": round(avg, 4), "launches": n, "tflops": round(tf, 2),
                                  "frac": round(tf / peak, 4)}
+        bd_ms, bd_n = PPO.profile_get("k_policy_bwd_data")
+        wg_ms, wg_n = PPO.profile_get("k_policy_wgrad")
+        if bd_n and wg_n and "k_policy_bwd" not in kernels:      # three-product backward (deep policies, small minibatches): the pair
+            pair_ms = bd_ms / bd_n + wg_ms / wg_n
+            tf = flops_per_state("bwd") * MINIBATCH / (pair_ms * 1e-3) / 1e12
+            kernels["k_policy_bwd_data+k_policy_wgrad"] = {"avg_ms": round(pair_ms, 4), "launches": bd_n, "tflops": round(tf, 2), "frac": round(tf / peak, 4)}
         if split_dw1 and "k_policy_bwd" in kernels:
             pair_ms = kernels["k_policy_bwd"]["avg_ms"] + kernels["k_policy_dw1"]["avg_ms"]
             tf = flops_per_state("bwd") * MINIBATCH / (pair_ms * 1e-3) / 1e12
@@ -424,22 +436,28 @@ def main():
             gbs = 17.0 * 128 * cols / (ms * 1e-3) / 1e9
             kernels["k_gae_tn@%dx128" % cols] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
                                                   "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
-        k = kernels.get("k_policy_bwd+k_policy_dw1") or kernels.get("k_policy_bwd")
+        k = kernels.get("k_policy_bwd+k_policy_dw1") or kernels.get("k_policy_bwd") or kernels.get("k_policy_bwd_data+k_policy_wgrad")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
             # inside this process); null when no pass was made for this exact launch shape
             traffic, tsrc = None, None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-                key = "%s|envs=%d|quads=%d|hid=%d" % (args.dtype, MINIBATCH, QUADS, HID)
+                # PPO_PMC_TRAFFIC_FILE: the measurement bundle points this at the PMC passes it has just made, so every line
+                # of a bundle carries its own bundle's figure (nothing is filled in afterwards)
+                pfile = os.environ.get("PPO_PMC_TRAFFIC_FILE") or os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+                pm = json.load(open(pfile))
+                key = "%s|envs=%d|quads=%d|hid=%d" % (args.dtype, MINIBATCH, QUADS, HID) + ("" if LAYERS == 2 else "|layers=%d" % LAYERS)
                 ent = pm["launch_shapes"].get(key)
                 if ent:
                     traffic = ent["k_policy_bwd_hbm_bytes"]
-                    tsrc = "profiles/%s [%s] (%s)" % (PMC_TRAFFIC_FILE, key, pm["source"])
+                    if split_dw1 and ent.get("k_policy_dw1_hbm_bytes"):
+                        traffic += ent["k_policy_dw1_hbm_bytes"]          # the roofline line is the backward PAIR
+                    tsrc = "%s [%s] (%s)" % (os.path.relpath(pfile, ROOT), key, pm["source"])
             except Exception:
                 pass
             tiles = MINIBATCH * (QUADS // 8)
-            roof = {"bound": "mfma", "kernel": "k_policy_bwd+k_policy_dw1 (the backward is two launches in this mode)" if split_dw1 else "k_policy_bwd",
+            roof = {"bound": "mfma", "kernel": "k_policy_bwd+k_policy_dw1 (the backward is two launches in this mode)" if split_dw1 else
+                    ("k_policy_bwd" if "k_policy_bwd" in kernels else "k_policy_bwd_data+k_policy_wgrad (three-product backward)"),
                     "achieved": k["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
@@ -486,9 +504,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%d parallel synthetic rand-poly-shaped envs per GPU (Q=%d,H=%d,A=%d,F=72 int8), "
-                                   "2x%d MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
+                                   "%dx%d MLP policy %s, T=%d steps/iteration, %d epochs, minibatch %d/GPU, "
                                    "gamma=1.0 eps=0.05 entropy_w=0.01 Adam 1e-4; returns mode (lambda=1,V=0)"
-                                   % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, HID, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
+                                   % (N_ENVS, QUADS, 4 * QUADS, 16 * QUADS, LAYERS, HID, "fp32" if args.dtype == "f32" else "bf16 MFMA / fp32 accumulate (config 5 arithmetic)",
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world,

@@ -20,7 +20,10 @@
  *    -Inf in the reference, test/quad_game_utilities.jl:39-44).
  *  - policy parameters are one flat float32 vector in Flux order (W1,b1, the num_hidden_layers-1 hidden->hidden
  *    (W,b) pairs, W_out,b_out), W stored [out,in] column-major, so Flux.params(policy) round-trips (test/policy.jl:9-19).
- *  - not re-entrant per handle; one host thread and one HIP stream per process (ppo_set_stream).
+ *  - one engine per HOST THREAD: the device (ppo_device_init), the stream (ppo_set_stream), the kernel timers, the RCCL
+ *    communicator and the error text are thread-local, so a process may run several engines side by side (one thread per
+ *    GPU); a handle belongs to the thread that created it and is not re-entrant.  The ppo_set_* tuning knobs are
+ *    process-wide.
  */
 #ifndef PPO_HIP_H
 #define PPO_HIP_H

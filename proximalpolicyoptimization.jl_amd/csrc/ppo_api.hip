@@ -10,15 +10,20 @@
 #include <mutex>
 
 
-// ---------------------------------------------------------------- globals
+// ---------------------------------------------------------------- engine state: ONE ENGINE PER HOST THREAD
+// Everything that makes up an engine instance -- the HIP device (hipSetDevice is per thread), the stream every kernel of
+// that engine is enqueued on, the kernel-timing tables, the RCCL communicator (ppo_rccl.hip), the last error text -- is
+// thread_local: a process may run several engines, one per host thread (e.g. one per GPU), each with its own stream and
+// communicator, and handles belong to the thread that created them ("one stream per engine handle").  What
+// stays process-wide are the tuning knobs (ppo_set_*) and the pinned-record pool of the disk sink (mutex-protected).
 static thread_local std::string g_err;
-static hipStream_t g_stream = nullptr;
-static bool g_own_stream = false;
-static bool g_init = false;
-static bool g_prof = false;
+static thread_local hipStream_t g_stream = nullptr;
+static thread_local bool g_own_stream = false;
+static thread_local bool g_init = false;
+static thread_local bool g_prof = false;
 struct ProfRec { hipEvent_t e0, e1; };
-static std::map<std::string, std::vector<ProfRec>> g_prof_pending;
-static std::map<std::string, std::pair<double, int64_t>> g_prof_done;
+static thread_local std::map<std::string, std::vector<ProfRec>> g_prof_pending;
+static thread_local std::map<std::string, std::pair<double, int64_t>> g_prof_done;
 
 void ppo_set_error(const std::string& msg) { g_err = msg; }
 hipStream_t ppo_stream() { return g_stream; }

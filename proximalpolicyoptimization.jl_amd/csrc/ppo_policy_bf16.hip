@@ -564,7 +564,7 @@ static int32_t dispatch_fwd_bf16(ppo_policy_s* p, const FwdArgs& args, int64_t B
         /* MODE 4: one env-snapshot slot per wave + the template rows behind them */                               \
         /* + the W2 queue's look-ahead past the last feature tile (the persistent form's env slots cover it there) */ \
         const size_t lds = FwdB<FF, HH>::lds_bytes + PPO_BF16_FWD_WQ * 1024 + (MODE == 4 ? (size_t)FWB_W * (2 * args.envV + 32) + 32 * PPO_TPL : 0); \
-        static size_t attr_lds = 0;                                                                                  \
+        static thread_local size_t attr_lds = 0;                                                                                  \
         if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<FF, HH, MODE, TT>,                            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
@@ -598,7 +598,7 @@ int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& a, int64
         size_t lds = FwdB<72, HH>::lds_bytes + env_bytes;                                                            \
         if (lds > 160 * 1024) return PPO_ERR_UNSUPPORTED;                                                            \
         lds = std::max(lds, (size_t)FwdB<72, HH>::W2_U4 * 16 + PPO_BF16_FWD_WQ * 1024);                              \
-        static size_t attr_lds = 0;                                                                                  \
+        static thread_local size_t attr_lds = 0;                                                                                  \
         if (lds > attr_lds) {                                                                                        \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_bf16<72, HH, 3, TT>,                               \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
@@ -1500,7 +1500,7 @@ int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_
     do {                                                                                                          \
         static_assert(BwdB<FF, HH>::NI <= BwdB<FF, HH>::NT, "X fragments are emitted by waves 0..NI-1");          \
         const size_t lds = BwdB<FF, HH>::total;                                                                   \
-        static bool attr_set = false;                                                                             \
+        static thread_local bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_bf16<FF, HH>,                                   \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \

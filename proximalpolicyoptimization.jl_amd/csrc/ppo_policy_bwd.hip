@@ -638,7 +638,7 @@ int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* id
         nwg = (int)(a.B < cap ? a.B : cap);                                                                   \
         p->nwg_bwd = nwg; p->nwg_small = 0;                                                                                     \
         const size_t lds = bwd_lds_bytes<FF, HH>();                                                           \
-        static bool attr_set = false;                                                                         \
+        static thread_local bool attr_set = false;                                                                         \
         if (!attr_set) {                                                                                      \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd<FF, HH>,                                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \

@@ -626,7 +626,7 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a, int tr_tail_wg = 0
     const size_t lds_data = sizeof(float) * (z2 + (size_t)2 * HID * SB_LD + 32 * 4 + (size_t)HID * 4);
     const size_t lds_deep = sizeof(float) * (2 * z2 + (size_t)HID * SB_LD + 32 * 4 + (size_t)HID * 4);
     const size_t lds_w = sizeof(float) * (size_t)4 * WT * 32 * SB_LD;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_data));
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_data_deep<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_deep));

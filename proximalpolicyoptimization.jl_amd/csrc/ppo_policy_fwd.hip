@@ -512,7 +512,7 @@ static int32_t dispatch_fwd_deep(ppo_policy_s* p, const FwdArgs& args, int64_t B
             ppo_set_error("compact rollouts need the built-in env's F = 72"); return PPO_ERR_UNSUPPORTED; \
         } else {                                                                                         \
             const size_t dlds = snap + (size_t)4 * (HH / 32) * 4096;                                     \
-            static size_t attr_lds = 0;                                                                  \
+            static thread_local size_t attr_lds = 0;                                                                  \
             if (dlds > attr_lds) {                                                                       \
                 HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd<FF, HH, MODE, TT, 1>,              \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));     \
@@ -650,7 +650,7 @@ int32_t launch_policy_rollout_persistent(ppo_policy_s* p, ppo_env_s* e, ppo_roll
     }
 #define LAUNCH3(HH, TT)                                                                                      \
     do {                                                                                                     \
-        static size_t attr_lds = 0;                                                                          \
+        static thread_local size_t attr_lds = 0;                                                                          \
         if (lds > attr_lds) {                                                                                \
             HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd<72, HH, 3, TT>,                            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \

@@ -202,7 +202,7 @@ template <int F, int HID, int CS>
 static int32_t launch_split(FwdArgs& a, int64_t B) {
     constexpr int NT = HID / 32;
     const size_t slots = CS ? (size_t)4 * (2 * a.envV + 32) : 0;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_split<F, HID, 4, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_split<F, HID, 2, CS>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

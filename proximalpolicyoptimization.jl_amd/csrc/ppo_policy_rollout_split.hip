@@ -252,7 +252,7 @@ static int32_t launch_rs(FwdArgs& a, int64_t N, int V) {
     a.env_slots = slots;
     const size_t lds = (size_t)G * NT * 4096 + (size_t)G * slots * (2 * V + 32);
     if (lds > 140 * 1024) return PPO_ERR_UNSUPPORTED;
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 4, ENV>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
         HIP_TRY(hipFuncSetAttribute((const void*)k_rollout_split<72, HID, 2, ENV>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));

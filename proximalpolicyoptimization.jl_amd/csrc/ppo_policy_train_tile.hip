@@ -321,7 +321,7 @@ static int32_t launch_tt(ppo_policy_s* p, TrainTileArgs& ta, int64_t B, int* nwg
     constexpr int NT = HID / 32;
     const size_t z2 = PPO_BWD_Z2ROW_AT(HID) ? (size_t)32 * (HID + 4) : (size_t)HID * TT_LD;
     const size_t lds = sizeof(float) * ((size_t)NT * 1024 + z2 + (size_t)2 * HID * TT_LD + 32 * 4 + (size_t)HID * 4 + (size_t)2 * NT * 16 * 4 + (size_t)2 * NT * 8 * 4);
-    static bool attr_set = false;
+    static thread_local bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_policy_train_tile<F, HID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;

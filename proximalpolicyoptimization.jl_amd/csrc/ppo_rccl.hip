@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace {
 typedef struct { char internal[128]; } rcclUniqueId;           // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
@@ -26,9 +27,11 @@ fn_all_reduce p_all_reduce = nullptr;
 fn_comm_destroy p_comm_destroy = nullptr;
 fn_error_string p_error_string = nullptr;
 fn_comm_count p_comm_count = nullptr, p_comm_user_rank = nullptr;
-rcclComm g_comm = nullptr;
+thread_local rcclComm g_comm = nullptr;      // one communicator per engine = per host thread (ppo_api.hip)
 
+std::mutex g_load_mu;
 int32_t load_rccl() {
+    std::lock_guard<std::mutex> lk(g_load_mu);
     if (g_lib) return PPO_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {

@@ -125,8 +125,11 @@ def _random_batch(P, pol, rng, B, F):
     return states, active, actions, p_old, adv
 
 
-@pytest.mark.parametrize("F,hid,L", CASES)
-@pytest.mark.parametrize("B", [5, 300, 1100])
+GRAD_CASES = [(F, hid, L, B) for (F, hid, L) in CASES for B in (5, 300)] + \
+    [(72, 128, 3, 1100), (72, 256, 3, 1100), (216, 256, 3, 1100), (72, 256, 1, 1100), (216, 256, 2, 1100)]
+
+
+@pytest.mark.parametrize("F,hid,L,B", GRAD_CASES)
 def test_deep_policy_gradient_vs_f64(P, orc, F, hid, L, B):
     """step_batch! gradient (src/train.jl:54-84) of a deep policy from host-supplied rollouts (any F): float64 oracle,
     tolerance 2e-5 of max|g| like the L = 2 kernels; ragged tile counts and more tiles than workgroups."""

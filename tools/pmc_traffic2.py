@@ -32,7 +32,12 @@ res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
 for arg in sys.argv[2:]:
     key, d = arg.rsplit("=", 1)
     ks = passes(d)
-    bwd = [v for k, v in ks.items() if k.startswith("k_policy_bwd")]
-    res["launch_shapes"][key] = {"k_policy_bwd_hbm_bytes": (bwd[0]["hbm_bytes"] if bwd else None), "kernels": ks}
+    bwd = [v for k, v in ks.items() if k.startswith("k_policy_bwd<") or k.startswith("k_policy_bwd_bf16")]
+    if not bwd:      # three-product backward (deep policies): the pair
+        pair = [v for k, v in ks.items() if k.startswith("k_policy_bwd_data") or k.startswith("k_policy_wgrad")]
+        bwd = [{"hbm_bytes": sum(v["hbm_bytes"] for v in pair)}] if pair else []
+    dw1 = [v for k, v in ks.items() if k.startswith("k_policy_dw1")]
+    res["launch_shapes"][key] = {"k_policy_bwd_hbm_bytes": (bwd[0]["hbm_bytes"] if bwd else None),
+                                 "k_policy_dw1_hbm_bytes": (dw1[0]["hbm_bytes"] if dw1 else None), "kernels": ks}
 json.dump(res, open(sys.argv[1], "w"), indent=1)
 print(json.dumps({k: v["k_policy_bwd_hbm_bytes"] for k, v in res["launch_shapes"].items()}, indent=1))
