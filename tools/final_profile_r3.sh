@@ -1,14 +1,16 @@
 #!/bin/bash
-# Round-3 measurement bundle (GPU box).  Part A (default): PMC passes FIRST (so every bench line of the bundle reads its own
-# bundle's HBM traffic through PPO_PMC_TRAFFIC_FILE -- nothing is filled in afterwards), then the headline bench and the
-# rocprofv3 kernel stats.  Part B ("b"): non-headline configs (bf16, config 4/5 shapes, HID = 128, deep policy, streaming,
-# strong-scaling shards, 2-rank rehearsal).
+# Round-3 measurement bundle (GPU box).  Part A (default): PMC passes FIRST, then the headline bench (which reads the HBM
+# traffic of those passes through PPO_PMC_TRAFFIC_FILE) and the rocprofv3 kernel stats.  tools/collect_profiles_r3.sh then
+# copies part A's pmc_traffic.json to profiles/r03_pmc_traffic.json, which travels to the box of part B ("b": non-headline
+# configs -- bf16, config 4/5 shapes, HID = 128, deep policy, streaming, strong-scaling shards, 2-rank rehearsal; a fresh box,
+# gpurun_out/ does not travel) and is what its bench lines read.  Every line carries the figure bench.py read itself;
+# nothing is filled in afterwards.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 F=gpurun_out/final3; mkdir -p $F
 B="python3 bench.py --no-cpu-baseline"
-export PPO_PMC_TRAFFIC_FILE=$GRAFT_REPO_ROOT/$F/pmc_traffic.json
 if [ "${1:-a}" = "a" ]; then
+  export PPO_PMC_TRAFFIC_FILE=$GRAFT_REPO_ROOT/$F/pmc_traffic.json
   rm -rf $F/trace $F/pmc
   A="--steps 1 --warmup 0 --t-steps 8 --epochs 1"
   P=$F/pmc/f32_4096

@@ -9,12 +9,14 @@ sys.path.insert(0, ROOT)
 import ppo_amd as PPO
 
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-out = {"workload": "4096 envs x 128 steps, Policy(72,256,2,4), 4 epochs, minibatch 4096, gamma 1.0, eps 0.05, "
+LAYERS = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # hidden layers (1..4); bf16 mode covers 2 only
+out = {"workload": "4096 envs x 128 steps, Policy(72,256,%d,4)," % LAYERS +
+       " 4 epochs, minibatch 4096, gamma 1.0, eps 0.05, "
                    "entropy_weight 0.01, Adam 3e-4, synthetic rand-poly-shaped env (Q=8, max_actions 32)", "runs": {}}
-for dtype in ("f32", "bf16"):
+for dtype in (("f32", "bf16") if LAYERS == 2 else ("f32",)):
     env = PPO.HipVecEnv(num_envs=4096, Q=8, max_actions=32, seed=7)
     ev = PPO.HipVecEnv(num_envs=1024, Q=8, max_actions=32, seed=99)
-    pol = PPO.HipPolicy(72, 256, 2, 4, seed=0, dtype=dtype)
+    pol = PPO.HipPolicy(72, 256, LAYERS, 4, seed=0, dtype=dtype)
     opt = PPO.Optimiser(PPO.Adam(3e-4))
     curve = []
     t0 = time.perf_counter()
@@ -35,4 +37,4 @@ for dtype in ("f32", "bf16"):
     ar = [c["average_return"] for c in curve if "average_return" in c]
     print(dtype, "average return", " -> ".join("%.2f" % a for a in ar))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "learning_curve.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "learning_curve%s.json" % ("" if LAYERS == 2 else "_%dlayers" % LAYERS)), "w"), indent=1)
