@@ -59,7 +59,8 @@ end
 set_dtype!(p::HipPolicy, dtype::Symbol) =
     check(ccall((:ppo_policy_set_dtype, LIB), Int32, (Ptr{Cvoid}, Int32), p.h, dtype === :bf16 ? 1 : 0))
 
-# Flux.params(policy) round trip: flat vector in Flux order (W1,b1,W2,b2,W3,b3), W [out,in] column-major
+# Flux.params(policy) round trip: flat vector in Flux order (W1,b1, the num_hidden_layers-1 hidden (W,b) pairs, W_out,b_out),
+# W [out,in] column-major; any num_hidden_layers in 1..4 (test/policy.jl:9-19)
 set_params!(p::HipPolicy, flat::Vector{Float32}) =
     check(ccall((:ppo_policy_set_params, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), p.h, flat))
 function get_params(p::HipPolicy)
@@ -84,6 +85,23 @@ function ensure!(r::HipRollouts, env::HipVecEnv, T)
         finalizer(x -> ccall((:ppo_rollouts_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), r)
     end
     r.h
+end
+
+# BufferRollouts for a user env whose state(env) rows are not the built-in env's (host-supplied columns: N columns of
+# [F, H] Int8 rows, any F the policy was created for -- e.g. the 216-feature level-4 template); filled with set_columns!
+function HipRollouts(N::Integer, H::Integer, F::Integer, T::Integer)
+    r = HipRollouts()
+    ref = Ref{Ptr{Cvoid}}()
+    check(ccall((:ppo_rollouts_create_shape, LIB), Int32, (Int64, Int32, Int32, Int64, Ref{Ptr{Cvoid}}), N, H, F, T, ref))
+    r.h = ref[]
+    finalizer(x -> ccall((:ppo_rollouts_destroy, LIB), Int32, (Ptr{Cvoid},), x.h), r)
+    r
+end
+function set_columns!(r::HipRollouts, states::Array{Int8}, active::Array{UInt32}, actions1, p_sel::Array{Float32}, returns::Array{Float32})
+    T = size(active, 2)                                # columns are [N, T] column-major == [T][N]
+    check(ccall((:ppo_rollouts_set, LIB), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Int8}, Ptr{UInt32}, Ptr{Int32}, Ptr{Float32}, Ptr{Float32}, Ptr{UInt8}),
+                r.h, T, states, active, Int32.(actions1 .- 1), p_sel, returns, C_NULL))
 end
 
 struct HipAdam; h::Ptr{Cvoid}; eta::Float64; end      # member of a Flux.Optimiser-like iterable
