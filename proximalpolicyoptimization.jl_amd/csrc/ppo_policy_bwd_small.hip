@@ -30,6 +30,7 @@ struct BwdSmallArgs {
     float4* dz2f; float4* dz1f;                             // [tile][feature tile][4][64] float4, like act1 / act2
     float* slabs; size_t slab_stride;
     int ksplit;                                             // K-slices of k_policy_wgrad
+    int xcd_map;                                            // 1: workgroup -> (block, slice) keeps a K-slice on ONE XCD (ksplit % 8 == 0)
     // any num_hidden_layers (test/policy.jl:9-19): L hidden layers, actl[l] / dzl[l] = saved output / dZ of hidden layer l
     // (l = 0 first, L - 1 last; L == 2: {act1, act2} / {dz1f, dz2f}), w2tp = the L - 1 packed W^T streams back to back
     int L;
@@ -447,7 +448,18 @@ __global__ __launch_bounds__(256, 2) void k_policy_wgrad(BwdSmallArgs a) {
     const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* const bufA = smem + (size_t)v * WT * TILE;                  // wave-private: A tiles first, then the B tiles
     const int NBH = (a.L - 1) * NB2;                                   // dW blocks of the L - 1 hidden->hidden layers
-    const int block = blockIdx.x % (NBH + NB1), slice = blockIdx.x / (NBH + NB1);
+    // Workgroup -> (output block, K-slice).  All blocks of a K-slice read the SAME row tiles (every dZ / H operand tile is
+    // used by NT/2 blocks), and the hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own
+    // L2: the plain mapping (block fastest) spreads a slice's blocks over all eight L2s, so every operand tile is filled
+    // eight times from the Infinity Cache.  XCD-aware mapping (xcd_map, opt-in): the workgroups that land on XCD x (ids x,
+    // x + 8, ...) walk the blocks of slices x, x + 8, ... one slice after the other, so a slice's tiles are fetched into
+    // ONE L2 once.  Measured slower (launch_small): the kernel is not bound by L2 fills -- with every workgroup of an XCD on
+    // the same few tiles at the same time their loads queue on the same L2 channels instead of spreading over all of them.
+    int block, slice;
+    if (a.xcd_map) {
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        slice = x + 8 * (i / (NBH + NB1)); block = i % (NBH + NB1);
+    } else { block = blockIdx.x % (NBH + NB1); slice = blockIdx.x / (NBH + NB1); }
     const int64_t per = (a.B + a.ksplit - 1) / a.ksplit;
     const int64_t t0 = (int64_t)slice * per, t1 = (t0 + per < a.B) ? t0 + per : a.B;
     float* slab = a.slabs + (size_t)slice * a.slab_stride;             // one partial per K-slice: the four waves' sums meet in LDS
@@ -640,6 +652,14 @@ static int32_t launch_small(ppo_policy_s* p, BwdSmallArgs& a, int tr_tail_wg = 0
     // K-slices: two workgroups per CU over the block list, all resident at once (a partial second round costs a whole one)
     int ks = 512 / blocks;
     if (ks < 1) ks = 1;
+    // XCD-aware block order (see k_policy_wgrad; needs a multiple of 8 slices): measured SLOWER and therefore off --
+    // gpurun_out/r3h, alternating on one box: wgrad 42.2 -> 47.4 us at 512 tiles, 27.6 -> 28.8 at 256, 410 -> 562 us for the
+    // three-layer policy at 4096 tiles (ks = 8 / 16 / 24 alike).  A/B knobs: PPO_WGRAD_XCD=1, PPO_WGRAD_KS=n
+    static const int xcd_on = [] { const char* v = getenv("PPO_WGRAD_XCD"); return v ? atoi(v) : 0; }();
+    static const int ks_force = [] { const char* v = getenv("PPO_WGRAD_KS"); return v ? atoi(v) : 0; }();
+    if (ks_force > 0) ks = ks_force;
+    a.xcd_map = 0;
+    if (xcd_on && ks >= 8 && a.B >= 8) { ks = (ks / 8) * 8; if ((int64_t)ks > a.B) ks = (int)(a.B / 8) * 8; a.xcd_map = 1; }
     if ((int64_t)ks > a.B) ks = (int)a.B;
     a.ksplit = ks;
     p->nwg_bwd = ks;                 // slabs holding weight-gradient partials (one per K-slice)
@@ -686,7 +706,7 @@ static int32_t bwd_small_impl(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t
     a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
     a.dz2f = (float4*)p->dz2f.p; a.dz1f = (float4*)p->dz1f.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID, p->L);
-    a.ksplit = 1;
+    a.ksplit = 1; a.xcd_map = 0;
     a.L = p->L;
     const size_t lstride = (size_t)p->cap_tiles * (p->HID / 32) * 256;             // float4 per saved layer
     for (int l = 0; l < 4; ++l) { a.actl[l] = nullptr; a.dzl[l] = nullptr; }
