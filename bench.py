@@ -57,7 +57,7 @@ def cpu_baseline():
     """The CPU restatement of the Julia path (oracle/, 1 core) timed on a bounded sample of the same workload:
     serial per-step forward/sample/step, serial scan, per-minibatch forward+backward+Adam."""
     from oracle import oracle as orc
-    n_env, T, B = 4, 48, 64
+    n_env, T, B = 6, 64, 96              # 384 env-steps: ~25 s of scalar C on one core (round 2 timed 192 in 12 s)
     params = orc.glorot_params(F, HID, 2, seed=0)
     env = orc.Env(Q=8, max_actions=T_STEPS, N=n_env, seed=1234)
     env.reset()
