@@ -49,6 +49,9 @@ def test_two_engines_in_one_process(ppo):
             assert np.array_equal(x, y), "engine %s differs from its single-threaded run" % k
         assert out[k][3] == ref[k][3] > 0, "each engine counts its own launches (thread-local timing tables)"
     # an error raised in one thread's engine does not leak into the other's error text
+    with pytest.raises(P.PPOError):
+        P.HipVecEnv(num_envs=4, Q=1)                           # this thread's last error: "env_create: bad sizes"
+    assert "env_create" in P._lib.last_error()
     err = {}
 
     def bad():
@@ -61,4 +64,4 @@ def test_two_engines_in_one_process(ppo):
     t.start()
     t.join()
     assert "policy_create" in err["bad"]
-    assert "policy_create" not in P._lib.last_error()
+    assert "env_create" in P._lib.last_error() and "policy_create" not in P._lib.last_error()
