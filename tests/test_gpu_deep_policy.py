@@ -125,8 +125,10 @@ def _random_batch(P, pol, rng, B, F):
     return states, active, actions, p_old, adv
 
 
-GRAD_CASES = [(F, hid, L, B) for (F, hid, L) in CASES for B in (5, 300)] + \
-    [(72, 128, 3, 1100), (72, 256, 3, 1100), (216, 256, 3, 1100), (72, 256, 1, 1100), (216, 256, 2, 1100)]
+# (the float64 oracle is scalar C on one host core: ~30 ms per state at HID = 256, L = 3 -- the batch sizes are chosen so the
+# whole file stays under two minutes; 600 > 512 tiles runs several tiles per workgroup in every kernel of the path)
+GRAD_CASES = [(F, hid, L, B) for (F, hid, L) in CASES for B in (5, 200)] + \
+    [(72, 128, 3, 600), (72, 256, 3, 600), (216, 256, 3, 600), (72, 256, 1, 600)]
 
 
 @pytest.mark.parametrize("F,hid,L,B", GRAD_CASES)
