@@ -93,7 +93,9 @@ def cpu_baseline_blas(threads=None):
     from oracle import oracle as orc
     from oracle import np_oracle as npo
     torch.set_num_threads(threads or min(16, os.cpu_count() or 1))   # a one-GPU box's CPU share is 16 cores
-    n_env, T, B = (64, 64, 1024) if threads != 1 else (32, 32, 256)
+    # ~10 s of CPU work each (round 2 timed 2 s / 0.7 s samples): 16,384 env-steps with the headline minibatch on 16 threads,
+    # 12,288 on one core
+    n_env, T, B = (128, 128, 4096) if threads != 1 else (96, 128, 2048)
     params = orc.glorot_params(F, HID, 2, seed=0)
     layers = [(torch.tensor(W, dtype=torch.float32, requires_grad=True), torch.tensor(b, dtype=torch.float32, requires_grad=True))
               for (W, b) in npo.unpack_params(params, F, HID, 2)]
