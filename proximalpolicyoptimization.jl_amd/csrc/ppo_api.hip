@@ -925,6 +925,10 @@ int32_t ppo_set_bwd_small_max_tiles(int64_t tiles) { g_bwd_small_max_tiles = til
 static int64_t g_train_tile_max_tiles = [] { const char* v = std::getenv("PPO_TRAIN_TILE_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_TRAIN_TILE_DEFAULT; }();
 int32_t ppo_set_train_tile_max_tiles(int64_t tiles) { g_train_tile_max_tiles = tiles < 0 ? PPO_TRAIN_TILE_DEFAULT : tiles; return PPO_OK; }
 
+// fused backward: weight-gradient products as split-fp32 ("bf16x6") MFMAs (ppo_policy_bwd_x6.hip).  PPO_BWD_SPLIT_BF16 overrides.
+static int g_bwd_split = [] { const char* v = std::getenv("PPO_BWD_SPLIT_BF16"); return v ? atoi(v) : 0; }();
+int ppo_bwd_split_enabled() { return g_bwd_split; }
+
 // ================================================================ training
 // B = number of 32-row tiles of the minibatch (states * H/32)
 static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {

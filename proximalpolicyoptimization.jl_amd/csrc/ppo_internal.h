@@ -224,6 +224,10 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
                                 int64_t B_global, double eps, double entropy_weight, const float* adv_col);
 int32_t launch_adv_normalise(const float* returns, const int32_t* idx_dev, int64_t B, float* adv_col);
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+// the same fused backward with its row contractions (dW2, dW1) as split-fp32 products on the bf16 matrix pipe
+// (ppo_policy_bwd_x6.hip); PPO_ERR_UNSUPPORTED: shape not covered
+int32_t launch_policy_bwd_x6(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
+extern "C" int ppo_bwd_split_enabled();
 // three-product backward for small minibatches (ppo_policy_bwd_small.hip); PPO_ERR_UNSUPPORTED: not covered
 int32_t launch_policy_bwd_small(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 // small minibatches: forward + loss + backward-data of a tile in one workgroup, then the weight-gradient kernel

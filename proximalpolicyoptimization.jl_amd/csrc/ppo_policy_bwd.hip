@@ -619,6 +619,10 @@ static size_t bwd_lds_bytes() {
 
 int32_t launch_policy_bwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
     if (p->dtype == PPO_DTYPE_BF16) return launch_policy_bwd_bf16(p, ro, idx_dev, B);
+    if (ppo_bwd_split_enabled()) {
+        const int32_t xs = launch_policy_bwd_x6(p, ro, idx_dev, B);
+        if (xs != PPO_ERR_UNSUPPORTED) return xs;
+    }
     BwdArgs a;
     a.tps = ro->H / 32;
     a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;

@@ -1,0 +1,532 @@
+// ppo_policy_bwd_x6.hip -- K11 (src/train.jl:65-79): the fused fp32 backward with its three big products
+//   dH1 = dZ2 W2      dW2 += dZ2^T H1      dW1 += dZ1^T X
+// on the bf16 matrix pipe as SPLIT-fp32 products ("bf16x6"); same inputs, same gradient slab as ppo_policy_bwd.hip.
+//
+// Why.  On gfx950 v_mfma_f32_32x32x2_f32 retires 64 flop/clk/SIMD and blocks the vector ALU while it runs;
+// v_mfma_f32_32x32x16_bf16 retires 1024 flop/clk/SIMD and leaves the vector ALU free for 24 of its 32 clocks.  An fp32
+// number is the exact sum of three bfloat16 numbers (a = a_h + a_m + a_l: each an RNE rounding of what the previous ones
+// left, |a_m| <= 2^-8 |a|, |a_l| <= 2^-17 |a|), a product of two bf16 numbers is exact in fp32, and the MFMA accumulates in
+// fp32.  So
+//     a b  =  a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_m b_m + a_l b_h)  +  O(2^-24 |a b|)
+// six bf16 MFMAs of k = 16 (192 clocks) stand for the eight fp32 MFMAs of k = 2 (512 clocks) that cover the same 16
+// contraction indices, with a truncation error of the order of ONE fp32 rounding -- the fp32 fma chain they replace
+// rounds once per index, this form once per MFMA.  Where one operand is exact in bf16 (the int8 state rows X) three
+// MFMAs do.  The gradient tests hold this kernel to the same 2e-5 max|g| bar against the float64 oracle as the
+// pure-fp32 kernel.
+//
+// Data flow per 32-row tile (wave w owns feature tile w of every product):
+//   A  H1 fragments (lane = row) -> three bf16 pieces -> row-major [row][32 features] images per feature tile
+//      (8-byte-chunk swizzle: ds_write_b64 fill and ds_read_b64_tr_b16 transposed reads both conflict-free);
+//      dZ2 = (dY W3) . lrelu'(H2), lane = row -> three pieces, which ARE A-operand fragments of the next product
+//      (k order = accumulator-register order; the W2 pieces are packed to match) -> lane-linear fragment images;
+//      H2^T -> fp32 tile (dW3 sums, and phase C); X -> bf16 [input][k-slot] image with a ONES column at input 72
+//      (db1 = the dW1 column of that input), zeros up to 96.
+//   B  dH1[row, k] = sum_f dZ2[row, f] W2[f, k]: A = the dZ2 fragments of all feature tiles (LDS), B = this wave's
+//      W2 piece stream from L2 (three passes: W_l x Z_h | W_m x Z_m, Z_h | W_h x Z_l, Z_m, Z_h -- one 4-register
+//      operand ring instead of three).  The result has lane = feature, registers = rows: dZ1 = dH1 . lrelu'(H1) (signs
+//      by transposed reads of the H1 image) is, split in three, already the A operand of
+//   D  dW1[w,:] += dZ1^T X : 3 input tiles x 2 k-steps x 3 pieces = 18 MFMAs
+//   C  dW2[w,:] += dZ2^T H1: A = this wave's dZ2^T, recomputed lane = feature from dY, W3 and the H2^T tile (two
+//      fp32 MFMAs + 16 multiplies -- cheaper than a transpose) and split; B = the H1 piece images read transposed:
+//      8 k-tiles x 2 k-steps x 6 = 96 MFMAs.
+// The next tile's layer-1 / layer-2 fragments arrive by LDS-DMA during phase C into regions only this wave touches
+// and that are dead by then (its dZ2 fragment images, its H2^T rows).
+#include "ppo_internal.h"
+#include "ppo_device.h"
+#include <cstdlib>
+
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
+typedef float xf32x2 __attribute__((ext_vector_type(2)));
+typedef short xs16x4 __attribute__((ext_vector_type(4)));
+typedef float pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ uint32_t x_pack(float lo, float hi) {             // v_cvt_pk_bf16_f32 (RNE)
+    const xf32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf16x2));
+}
+__device__ __forceinline__ f32x16 x_mfma(const uint4& a, const uint4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, a), __builtin_bit_cast(xbf16x8, b), c, 0, 0, 0);
+}
+// four fp32 values -> three packed bf16 pieces (two dwords each): a = h + m + l exactly up to 2^-26 |a|
+__device__ __forceinline__ void x_split4(const float (&a)[4], uint2& ph, uint2& pm, uint2& pl) {
+    uint32_t P[2], M[2], L[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float a0 = a[2 * u], a1 = a[2 * u + 1];
+        P[u] = x_pack(a0, a1);
+        const float r0 = a0 - __uint_as_float(P[u] << 16), r1 = a1 - __uint_as_float(P[u] & 0xFFFF0000u);      // exact
+        M[u] = x_pack(r0, r1);
+        const float s0 = r0 - __uint_as_float(M[u] << 16), s1 = r1 - __uint_as_float(M[u] & 0xFFFF0000u);      // exact
+        L[u] = x_pack(s0, s1);
+    }
+    ph = make_uint2(P[0], P[1]); pm = make_uint2(M[0], M[1]); pl = make_uint2(L[0], L[1]);
+}
+// two fp32 registers that hold exact bf16 values -> one packed dword {lo16 = a, hi16 = b}
+__device__ __forceinline__ uint32_t x_perm(float a, float b) {
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+// two transposed 4x16 block reads -> one 32x32x16 operand fragment
+__device__ __forceinline__ uint4 x_tr_frag(const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) xs16x4 lds_s16x4;
+    const xs16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    const xs16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    const uint2 a = __builtin_bit_cast(uint2, u0), b = __builtin_bit_cast(uint2, u1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+struct BwdXArgs {
+    const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
+    int tps; int x_by_tile;
+    const float4* act1; const float4* act2; const float4* dY;
+    const float4* w2tp; const float4* w3p;
+    float* slabs; size_t slab_stride;
+};
+
+template <int F, int HID>
+struct XCfg {
+    static_assert(F == 72, "state rows of 72 features (+ the ones column, zero padded to 96)");
+    static constexpr int NT = HID / 32;
+    static constexpr bool Z2R = PPO_BWD_Z2ROW_AT(HID);
+    static constexpr bool DMA1 = HID >= 256;                 // layer-1 fragments by LDS-DMA into the wave's own dZ2 slice
+    static_assert(!(DMA1 && Z2R), "the DMA landing zone is a feature-major slice");
+    static constexpr int LD = 36, RS = HID + 4;
+    static constexpr int WG_PER_CU = HID == 128 ? 2 : 1;
+    static constexpr int XROW = 80;                          // bytes per input row of the X image (32 k-slots of bf16 + pad: 16-byte reads conflict-free)
+    static constexpr int NIX = 3;                            // input tiles: 72 features, ones at 72, zeros to 96
+    static constexpr size_t oZ2 = 0, szZ2 = sizeof(float) * (Z2R ? 32 * RS : HID * LD);
+    static constexpr size_t oH2 = oZ2 + szZ2, szH2 = sizeof(float) * HID * LD;
+    static constexpr size_t oH1 = oH2 + szH2, szH1 = (size_t)3 * NT * 2048;        // [piece][feature tile][32 rows][64 B]
+    static constexpr size_t oX = oH1 + szH1, szX = (size_t)32 * NIX * XROW;
+    static constexpr size_t oDY = oX + szX, oW3 = oDY + 512, oID = oW3 + (size_t)HID * 16, total = oID + 2048;
+    static_assert(total <= 160 * 1024 / WG_PER_CU, "LDS budget");
+};
+
+template <int F, int HID>
+__global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
+    using C = XCfg<F, HID>;
+    constexpr int NT = C::NT, NTHR = NT * 64, LD = C::LD, RS = C::RS, NIX = C::NIX, XROW = C::XROW;
+    constexpr bool Z2R = C::Z2R, DMA1 = C::DMA1;
+    constexpr int XQW = 32 * F / 8, XPD = (XQW + NTHR - 1) / NTHR;
+    constexpr int PF = (HID >= 256) ? 2 : 4, S4 = HID / 8;
+    static_assert(S4 % (2 * PF) == 0 && NTHR >= 256 && NTHR >= HID, "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    float* const sZ2 = reinterpret_cast<float*>(smem_c + C::oZ2);
+    float* const sH2 = reinterpret_cast<float*>(smem_c + C::oH2);
+    char* const imgH1 = smem_c + C::oH1;
+    char* const imgX = smem_c + C::oX;
+    float* const sDY = reinterpret_cast<float*>(smem_c + C::oDY);
+    float* const sW3 = reinterpret_cast<float*>(smem_c + C::oW3);
+    uint4* const sID = reinterpret_cast<uint4*>(smem_c + C::oID);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    f32x16 accW2[NT], accW1[NIX];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW2[kt][r] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < NIX; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW1[it][r] = 0.0f;
+    float db2 = 0.f, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
+
+    if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
+        const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
+        *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
+    }
+    // identity B operands of the transposing MFMAs: k-slot (step s, lane half hB, element e) carries feature
+    // 16s + 8(e>>2) + 4hB + (e&3) of a packed accumulator tile, so lane (n, hB) holds a single 1.0 -- in step n>>4,
+    // element 4((n>>3)&1) + (n&3), and only if hB == (n>>2)&1
+    if (tid < 64) {
+        const int n = tid & 31, hB = tid >> 5, e = 4 * ((n >> 3) & 1) + (n & 3);
+#pragma unroll
+        for (int s1 = 0; s1 < 2; ++s1) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (hB == ((n >> 2) & 1) && s1 == (n >> 4)) {
+                const uint32_t one = (e & 1) ? 0x3F800000u : 0x00003F80u;
+                if ((e >> 1) == 0) v.x = one; else if ((e >> 1) == 1) v.y = one; else if ((e >> 1) == 2) v.z = one; else v.w = one;
+            }
+            sID[s1 * 64 + tid] = v;
+        }
+    }
+    // X image: zero, ones in the 32 k-slots of input 72 (never written again: the staging below touches inputs < 72)
+    for (int i = tid; i < 32 * NIX * XROW / 4; i += NTHR) {
+        const int row = i / (XROW / 4), c = i % (XROW / 4);
+        reinterpret_cast<uint32_t*>(imgX)[i] = (row == F && c < 16) ? 0x3F803F80u : 0u;
+    }
+    __syncthreads();
+
+    const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
+    const unsigned lo16 = (unsigned)lane * 16u;
+    const unsigned fb = (unsigned)(32 * w + 4 * h);
+    float* const h2slice = sH2 + (size_t)(32 * w) * LD;
+    float* const z2slice = sZ2 + (size_t)(32 * w) * LD;             // DMA1 only (feature-major dZ2: rows [32w, 32w+32) are this wave's)
+    const unsigned h2slice_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)h2slice);
+    const unsigned z2slice_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)z2slice);
+    // LDS-DMA of a tile's fragments (4 x 1 KiB, lane-linear) into a slice that only this wave touches; issued from inline
+    // asm and waited for with an explicit vmcnt(0) in phase A (see ppo_policy_bwd.hip for why hipcc must not know)
+    auto dma_frag = [&](const float4* base, int64_t t, unsigned dst_lds) {
+        const float4* src = base + ((size_t)t * NT + w) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned keep;
+            const float4* gsrc = src + q * 64;
+            const unsigned dst = dst_lds + (unsigned)q * 1024u;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+    };
+    float4 v1[4], dy;
+    uint2 xd[XPD];
+    auto issue_tile_loads = [&](int64_t t, int sidx) {
+        if constexpr (!DMA1) {
+            const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)t * NT + w) * 4 * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                typedef float f32x4l __attribute__((ext_vector_type(4)));
+                const f32x4l t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4l*>(s1 + (lo16 + (unsigned)q * 1024u)));
+                v1[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
+            }
+        }
+        dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+        const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
+#pragma unroll
+        for (int i = 0; i < XPD; ++i) {
+            const unsigned u = (unsigned)tid + (unsigned)i * NTHR;
+            const unsigned d = (u & 31u) * (unsigned)(F / 8) + (u >> 5);      // lane -> row, 32-lane group -> one 8-feature unit
+            xd[i] = u < (unsigned)XQW ? *reinterpret_cast<const uint2*>(xs + d * 8u) : make_uint2(0u, 0u);
+        }
+    };
+    if ((int64_t)blockIdx.x < a.B) {
+        dma_frag(a.act2, blockIdx.x, h2slice_lds);
+        if constexpr (DMA1) dma_frag(a.act1, blockIdx.x, z2slice_lds);
+        issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
+    }
+
+    for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        unsigned lb = fb * LD + j;
+        asm volatile("" : "+v"(lb));                               // per-tile opaque base: nothing derived from it is hoisted and spilled
+        float* const z2b = sZ2 + lb;
+        float* const h2b = sH2 + lb;
+        // this lane's 8-byte chunks in the H1 piece images of feature tile w: row j, chunk (2q + h) ^ ((j >> 2) & 7)
+        unsigned hw = (unsigned)(w * 2048 + 64 * j);
+        asm volatile("" : "+v"(hw));
+        const unsigned cx = (unsigned)(j >> 2) & 7u;
+        // ================= phase A: stage the tile
+        float4 v2[4];
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // everything this wave has in flight (DMAs included)
+            if constexpr (DMA1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v1[q] = *reinterpret_cast<const float4*>(z2slice + q * 256 + lane * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v2[q] = *reinterpret_cast<const float4*>(h2slice + q * 256 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // H1 (lane = row j, register 4q+e <-> feature e + 8q + 4h of tile w) -> three bf16 pieces -> images
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float hv[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+            uint2 ph, pm, pl;
+            x_split4(hv, ph, pm, pl);
+            const unsigned off = hw + 8u * (((unsigned)(2 * q + h)) ^ cx);
+            *reinterpret_cast<uint2*>(imgH1 + off) = ph;
+            *reinterpret_cast<uint2*>(imgH1 + NT * 2048 + off) = pm;
+            *reinterpret_cast<uint2*>(imgH1 + 2 * NT * 2048 + off) = pl;
+        }
+        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        {
+            f32x16 dh2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh2[r] = 0.0f;
+            const float w3a0 = sW3[(32 * w + j) * 4 + h], w3a1 = sW3[(32 * w + j) * 4 + 2 + h];
+            dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a0, h ? dy.y : dy.x, dh2, 0, 0, 0);
+            dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a1, h ? dy.w : dy.z, dh2, 0, 0, 0);
+            float* const z2r = sZ2 + j * RS + fb;                      // Z2R: this lane's row, features 32w + 4h + 8q .. +3
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = e + 8 * q;
+                    z[e] = dh2[4 * q + e] * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                    if constexpr (!Z2R) z2b[fo * LD] = z[e];
+                    h2b[fo * LD] = h2v[e];
+                }
+                if constexpr (Z2R) *reinterpret_cast<float4*>(z2r + 8 * q) = make_float4(z[0], z[1], z[2], z[3]);
+            }
+        }
+        // state rows -> bf16 X image [input][k-slot]; tile row R sits in k-slot R with bits 2 and 3 swapped (the row order
+        // the identity-MFMA transpose of dZ1 leaves in phase D's A operands)
+#pragma unroll
+        for (int i = 0; i < XPD; ++i) {
+            const int d = tid + i * NTHR;
+            if (d < XQW) {
+                const int row = d & 31, c = d >> 5;
+                const int slot = (row & 19) | ((row & 4) << 1) | ((row & 8) >> 1);
+                const uint32_t xw[2] = {xd[i].x, xd[i].y};
+                char* const xp = imgX + (8 * c) * XROW + 2 * slot;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = (float)(int)(int8_t)(xw[e >> 2] >> (8 * (e & 3)));
+                    *reinterpret_cast<uint16_t*>(xp + e * XROW) = (uint16_t)(__float_as_uint(xv) >> 16);     // |x| <= 128: exact in bf16
+                }
+            }
+        }
+        __syncthreads();
+        // ================= phase B: small VALU grads, dH1 = W2^T dZ2 (fp32 MFMA), dZ1, transposed, dW1
+        auto small_grads = [&]() {
+            const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
+            const float* gy = sDY + 64 * h;
+            pk2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
+#pragma unroll 1
+            for (int rc = 0; rc < 16; rc += 4) {
+                const float4 h4 = *reinterpret_cast<const float4*>(gh + rc);
+                const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+                float4 y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = *reinterpret_cast<const float4*>(gy + (rc + i) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const pk2 hh2 = {hv[i], hv[i]};
+                    d01 = pk_fma(pk2{y[i].x, y[i].y}, hh2, d01); d23 = pk_fma(pk2{y[i].z, y[i].w}, hh2, d23);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            dw3[0] += d01.x; dw3[1] += d01.y; dw3[2] += d23.x; dw3[3] += d23.y;
+            if (tid < 4) {
+                float s = 0.f;
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                db3 += s;
+            }
+        };
+        float4 ringA[PF], ringB[PF];
+#pragma unroll
+        for (int g = 0; g < PF; ++g) ringA[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
+        const bool grads_first = (2 * w < NT);
+        const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;
+        if (grads_first) small_grads();
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float* bz = Z2R ? sZ2 + j * RS + 4 * h : sZ2 + h * LD + j;
+            const char* wn = w2t + (size_t)PF * 1024;
+            auto mfma_set = [&](const float4 (&rg)[PF]) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    float b[4];
+                    if constexpr (Z2R) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bz + 8 * u);
+                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
+                }
+                bz += Z2R ? 8 * PF : 8 * PF * LD;
+            };
+#pragma unroll 1
+            for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringB[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));
+                wn += (size_t)PF * 1024;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ringA[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));   // tail padding covers the over-read
+                wn += (size_t)PF * 1024;
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_set(ringB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // dZ1 = dH1 . lrelu'(H1): the sign of H1 from the first piece of its image (this wave's own tile, row j)
+            uint2 zh[4], zm[4], zl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 hp = *reinterpret_cast<const uint2*>(imgH1 + hw + 8u * (((unsigned)(2 * q + h)) ^ cx));
+                const float z1[4] = {acc[4 * q + 0] * ((int16_t)(hp.x & 0xFFFFu) > 0 ? 1.0f : 0.01f),
+                                     acc[4 * q + 1] * ((int32_t)hp.x >= 0x10000 ? 1.0f : 0.01f),
+                                     acc[4 * q + 2] * ((int16_t)(hp.y & 0xFFFFu) > 0 ? 1.0f : 0.01f),
+                                     acc[4 * q + 3] * ((int32_t)hp.y >= 0x10000 ? 1.0f : 0.01f)};
+                x_split4(z1, zh[q], zm[q], zl[q]);
+            }
+            // ================= phase D: dW1[k,i] += sum_rows dZ1[k,row] * X[i,row]   (wave w: k-tile w; input 72 = ones: db1)
+            const uint4 id0 = sID[lane], id1 = sID[64 + lane];
+            const char* const xb = imgX + j * XROW + 16 * h;           // k-slots 16s + 8h .. +7 of input 32 it + j
+#pragma unroll
+            for (int p = 2; p >= 0; --p) {                              // smallest piece first
+                const uint2* zp = p == 0 ? zh : (p == 1 ? zm : zl);
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+                t = x_mfma(make_uint4(zp[0].x, zp[0].y, zp[1].x, zp[1].y), id0, t);
+                t = x_mfma(make_uint4(zp[2].x, zp[2].y, zp[3].x, zp[3].y), id1, t);
+                // lane (feature 32w + j, half h), register r: dZ1 piece of tile row (r&3) + 8(r>>2) + 4h, an exact bf16 value
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const uint4 af = make_uint4(x_perm(t[8 * s + 0], t[8 * s + 1]), x_perm(t[8 * s + 2], t[8 * s + 3]),
+                                                x_perm(t[8 * s + 4], t[8 * s + 5]), x_perm(t[8 * s + 6], t[8 * s + 7]));
+#pragma unroll
+                    for (int it = 0; it < NIX; ++it) {
+                        const uint4 bx = *reinterpret_cast<const uint4*>(xb + 32 * it * XROW + 32 * s);
+                        accW1[it] = x_mfma(af, bx, accW1[it]);
+                    }
+                }
+            }
+        }
+        if (!grads_first) small_grads();
+        // every wave is through with the whole dZ2 tile (B operands of the chain) and with its own H2 rows: the slices
+        // become DMA landing zones below
+        __syncthreads();
+        // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
+        {
+            // A operand: rows 16s + 8h .. +7 of this lane's feature 32w + j, fp32 from the dZ2 tile, split here
+            uint4 ah[2], am[2], al[2];
+            float s2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float zv[8];
+                if constexpr (Z2R) {
+                    const float* pa = sZ2 + (16 * s + 8 * h) * RS + 32 * w + j;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zv[e] = pa[e * RS];
+                } else {
+                    const float* pa = sZ2 + (32 * w + j) * LD + 16 * s + 8 * h;
+                    const float4 z0 = *reinterpret_cast<const float4*>(pa), z1 = *reinterpret_cast<const float4*>(pa + 4);
+                    zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s2 += zv[e];
+                const float lo4[4] = {zv[0], zv[1], zv[2], zv[3]}, hi4[4] = {zv[4], zv[5], zv[6], zv[7]};
+                uint2 p0, m0, l0, p1, m1, l1;
+                x_split4(lo4, p0, m0, l0);
+                x_split4(hi4, p1, m1, l1);
+                ah[s] = make_uint4(p0.x, p0.y, p1.x, p1.y); am[s] = make_uint4(m0.x, m0.y, m1.x, m1.y); al[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+            db2 += s2;
+            // the next tile's inputs: fragments by LDS-DMA into the (now idle) slices, dY and the state dwords into registers
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of its slices have returned
+            dma_frag(a.act2, ntile, h2slice_lds);
+            if constexpr (DMA1) dma_frag(a.act1, ntile, z2slice_lds);
+            {
+                int nidx = 0;
+                if (!a.x_by_tile) {
+                    const int32_t* ip = a.idx + ntile / a.tps;
+                    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nidx) : "s"(ip) : "memory");
+                }
+                issue_tile_loads(ntile, nidx);
+            }
+            // B operands: H1 pieces of k-tile kt, transposed reads.  16-lane group G = lane >> 4 takes columns 16(G&1) ..
+            // of rows r0 .. r0+3, r0 = 16s + 8h + 4u; lane 4q + p of the group addresses row r0 + q, 8-byte chunk 4(G&1) + p
+            unsigned tb[2][2];
+            {
+                const unsigned q4 = ((unsigned)lane & 15u) >> 2, p4 = (unsigned)lane & 3u, g1 = ((unsigned)lane >> 4) & 1u;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned r0 = 16u * s + 8u * h + 4u * u;
+                        tb[s][u] = 64u * (r0 + q4) + 8u * ((4u * g1 + p4) ^ ((r0 >> 2) & 7u));
+                    }
+                asm volatile("" : "+v"(tb[0][0]), "+v"(tb[0][1]), "+v"(tb[1][0]), "+v"(tb[1][1]));
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* i0 = imgH1 + kt * 2048;
+                    const uint4 bh = x_tr_frag(i0 + tb[s][0], i0 + tb[s][1]);
+                    const uint4 bm = x_tr_frag(i0 + NT * 2048 + tb[s][0], i0 + NT * 2048 + tb[s][1]);
+                    const uint4 bl = x_tr_frag(i0 + 2 * NT * 2048 + tb[s][0], i0 + 2 * NT * 2048 + tb[s][1]);
+                    accW2[kt] = x_mfma(al[s], bh, accW2[kt]);
+                    accW2[kt] = x_mfma(am[s], bm, accW2[kt]);
+                    accW2[kt] = x_mfma(ah[s], bl, accW2[kt]);
+                    accW2[kt] = x_mfma(am[s], bh, accW2[kt]);
+                    accW2[kt] = x_mfma(ah[s], bm, accW2[kt]);
+                    accW2[kt] = x_mfma(ah[s], bh, accW2[kt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ================= write the slab (fragment order; k_grad_reduce maps it to Flux order)
+    constexpr int FP = 96, NI = FP / 32;
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    float* sW2 = slab;                                   // [(ft*NT+kt)*16 + r][64]
+    float* sW1 = sW2 + (size_t)HID * HID;                // [(ft*NI+it)*16 + r][64]
+    float* sb1 = sW1 + (size_t)HID * FP;
+    float* sb2 = sb1 + HID;
+    float* sw3 = sb2 + HID;                              // [HID][4]
+    float* sb3 = sw3 + HID * 4;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sW2[((size_t)(w * NT + kt) * 16 + r) * 64 + lane] = accW2[kt][r];
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = accW1[it][r];
+    // db1[k] = dW1[k][input 72] (the ones column): column 8 of input tile 2, held by lanes 8 and 40
+    if (j == F - 64) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb1[32 * w + (r & 3) + 8 * (r >> 2) + 4 * h] = accW1[2][r];
+    }
+    {   // combine the two row halves (lanes l and l^32 own the same feature)
+        db2 += __shfl_xor(db2, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw3[i] += __shfl_xor(dw3[i], 32);
+        if (h == 0) {
+            const int f = 32 * w + j;
+            sb2[f] = db2;
+            *reinterpret_cast<float4*>(&sw3[f * 4]) = make_float4(dw3[0], dw3[1], dw3[2], dw3[3]);
+        }
+    }
+    if (tid < 4) sb3[tid] = db3;
+}
+
+int32_t launch_policy_bwd_x6(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
+    BwdXArgs a;
+    a.tps = ro->H / 32;
+    a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
+    a.idx = idx_dev; a.B = B * a.tps;
+    a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
+    a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
+    a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
+    int nwg = 0;
+    ProfScope ps("k_policy_bwd");
+#define LAUNCH(FF, HH)                                                                                        \
+    do {                                                                                                      \
+        const int64_t cap = 256 * XCfg<FF, HH>::WG_PER_CU;                                                    \
+        nwg = (int)(a.B < cap ? a.B : cap);                                                                   \
+        p->nwg_bwd = nwg; p->nwg_small = 0;                                                                   \
+        const size_t lds = XCfg<FF, HH>::total;                                                               \
+        static thread_local bool attr_set = false;                                                            \
+        if (!attr_set) {                                                                                      \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_bwd_x6<FF, HH>,                                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL((k_policy_bwd_x6<FF, HH>), dim3(nwg), dim3(HH * 2), lds, ppo_stream(), a);          \
+    } while (0)
+    if (p->F == 72 && p->HID == 256) LAUNCH(72, 256);
+    else if (p->F == 72 && p->HID == 128) LAUNCH(72, 128);
+    else return PPO_ERR_UNSUPPORTED;
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}
