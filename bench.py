@@ -53,6 +53,20 @@ def flops_per_state(kind):
     return 2 * rows * (2 * HID * HID + HID * F + 2 * HID * 4)
 
 
+def split_backward_on(dtype):
+    """True when the fused backward of this run is the split-fp32 (bf16x6) kernel (csrc/ppo_policy_bwd_x6.hip): fp32
+    policies with two hidden layers; PPO_BWD_SPLIT_BF16=0 selects the pure fp32-MFMA kernel."""
+    return dtype == "f32" and LAYERS == 2 and os.environ.get("PPO_BWD_SPLIT_BF16", "1") != "0"
+
+
+def split_backward_mfma_flops_per_state():
+    """bf16 MFMA flops the split-fp32 backward EXECUTES per 32-row tile: six piece products per fp32 product for
+    dH1 = dZ2 W2 and dW2 += dZ2^T H1, three for dW1 += dZ1^T X (X is exact in bf16; 72 inputs + the ones column padded
+    to 96).  The identity-MFMA transposes and the two small fp32 MFMAs are not counted."""
+    rows = 4 * QUADS
+    return 2 * rows * (6 * HID * HID + 6 * HID * HID + 3 * HID * 96)
+
+
 def cpu_baseline():
     """The CPU restatement of the Julia path (oracle/, 1 core) timed on a bounded sample of the same workload:
     serial per-step forward/sample/step, serial scan, per-minibatch forward+backward+Adam."""
@@ -438,6 +452,28 @@ def main():
             gbs = 17.0 * 128 * cols / (ms * 1e-3) / 1e9
             kernels["k_gae_tn@%dx128" % cols] = {"avg_ms": round(ms, 4), "GB/s": round(gbs, 1),
                                                   "frac_of_hbm_8TBs": round(gbs / 8000.0, 4)}
+        # the split-fp32 backward: the same iteration once more through the pure fp32-MFMA kernel (outside the timed region),
+        # so the line carries both forms of the dominant kernel measured in the same process
+        fp32_form = None
+        split_on = split_backward_on(args.dtype) and "k_policy_bwd" in kernels
+        if split_on and not use_dist:
+            PPO.set_bwd_split_bf16(False)
+            PPO.profile_enable(True)
+            iteration(args.warmup + args.steps + 1)
+            PPO.synchronize()
+            ms, n = PPO.profile_get("k_policy_bwd")
+            PPO.profile_enable(False)
+            PPO.set_bwd_split_bf16(None)
+            if n:
+                tf = flops_per_state("bwd") * MINIBATCH / (ms / n * 1e-3) / 1e12
+                fp32_form = {"kernel": "k_policy_bwd<F,HID> (v_mfma_f32_32x32x2_f32: ppo_set_bwd_split_bf16(0))", "avg_ms": round(ms / n, 4),
+                             "launches": n, "tflops": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if split_on:
+            kk = kernels["k_policy_bwd"]
+            ratio = split_backward_mfma_flops_per_state() / flops_per_state("bwd")
+            kk["executed_bf16_mfma_tflops"] = round(kk["tflops"] * ratio, 1)
+            kk["frac"] = round(kk["tflops"] * ratio / PEAK_BF16_MFMA_TFLOPS, 4)           # of the pipe that bounds it
+            kk["algorithmic_over_fp32_mfma_peak"] = round(kk["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
         k = kernels.get("k_policy_bwd+k_policy_dw1") or kernels.get("k_policy_bwd") or kernels.get("k_policy_bwd_data+k_policy_wgrad")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
@@ -460,12 +496,23 @@ def main():
             tiles = MINIBATCH * (QUADS // 8)
             roof = {"bound": "mfma", "kernel": "k_policy_bwd+k_policy_dw1 (the backward is two launches in this mode)" if split_dw1 else
                     ("k_policy_bwd" if "k_policy_bwd" in kernels else "k_policy_bwd_data+k_policy_wgrad (three-product backward)"),
-                    "achieved": k["tflops"], "peak": peak,
+                    "achieved": k["tflops"],
+                    # split-fp32 backward: `achieved` stays the ALGORITHMIC fp32 flops per second; the pipe that bounds the
+                    # kernel is the bf16 MFMA, which executes `mfma_flops_per_algorithmic_flop` flops per algorithmic flop,
+                    # so the peak of this algorithm in algorithmic flops is the bf16 dense peak divided by that ratio
+                    "peak": (round(PEAK_BF16_MFMA_TFLOPS * flops_per_state("bwd") / split_backward_mfma_flops_per_state(), 1) if split_on else peak),
                     "unit": "TFLOP/s", "frac": k["frac"], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                     "traffic_source": tsrc,
+                    "form": (None if not split_on else
+                             "split-fp32 (bf16x6) on v_mfma_f32_32x32x16_bf16: every fp32 operand is the exact sum of three bf16 pieces, "
+                             "six piece products with fp32 accumulation per fp32 product (three where X is exact in bf16); peak = %.0f TFLOP/s "
+                             "bf16 dense / %.2f executed MFMA flops per algorithmic flop; the same kernel's algorithmic rate is %.2fx the "
+                             "fp32-MFMA peak of %.1f TFLOP/s" % (PEAK_BF16_MFMA_TFLOPS, split_backward_mfma_flops_per_state() / flops_per_state("bwd"),
+                                                               k["tflops"] / PEAK_FP32_MFMA_TFLOPS, PEAK_FP32_MFMA_TFLOPS)),
+                    "fp32_mfma_form": fp32_form,
                     # context for `frac` (profiles/history/r01_mfma_f32_valu_overlap.txt): on gfx950 the fp32 MFMA
                     # runs on the packed-fp32 vector ALU and vector instructions do not hide under it
-                    "ceiling_note": None if args.dtype != "f32" else
+                    "ceiling_note": None if (args.dtype != "f32" or split_on) else
                     "pure v_mfma_f32_32x32x2_f32 chain measured 140-143 TFLOP/s on this chip (clock under load); every "
                     "vector instruction between MFMAs adds ~2 ns per SIMD: instruction-mix ceiling of this kernel "
                     "(2432 MFMA + ~5250 vector instr per tile) ~125-130 TFLOP/s",
@@ -512,7 +559,11 @@ def main():
                                       T_STEPS, EPOCHS, MINIBATCH),
                        "envs_per_gpu": N_ENVS, "T": T_STEPS, "epochs": EPOCHS, "minibatch_per_gpu": MINIBATCH,
                        "parallelism": "dp%d" % world,
-                       "rollouts_streamed_to_disk": bool(args.stream)},
+                       "rollouts_streamed_to_disk": bool(args.stream),
+                       # fp32 data, fp32 accumulation everywhere; the fused backward's three big products run as split-fp32
+                       # (three exact bf16 pieces per operand, six piece products) on the bf16 matrix pipe unless switched off
+                       "backward_products": ("split-fp32 (bf16x6) on the bf16 MFMA pipe, fp32 accumulate" if split_backward_on(args.dtype)
+                                             else ("fp32 MFMA" if args.dtype == "f32" else "bf16 MFMA"))},
             "allreduce": (dp.hook_kind if use_dist else None), "rccl_ranks": (comm[1] if comm else None),
             "strong": strong,
             "roofline": roof, "kernels": kernels, "reduced_profiling_run": reduced, "headline_config": not nonheadline,

@@ -225,6 +225,13 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
  * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
  * keeps every weight gradient resident in MFMA accumulators.  Default 384 (-1 restores it), 0 = always fused. */
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
+/* fp32 policies, fused backward (Policy(72, h, 2, 4)): 1 = its three big products (dH1 = dZ2 W2, dW2 += dZ2^T H1,
+ * dW1 += dZ1^T X) run on the bf16 matrix pipe as SPLIT-fp32 products -- every fp32 operand is the exact sum of three
+ * bfloat16 pieces, six piece products (fp32 accumulation) carry a product to one fp32 rounding -- instead of on the 16x
+ * slower fp32 matrix instructions; 0 = the pure fp32-MFMA kernel; -1 = the default (environment PPO_BWD_SPLIT_BF16, else
+ * on).  Same inputs, same gradient slab; gradients agree with the other form to fp32 rounding and meet the same 2e-5 max|g|
+ * bar against the float64 restatement. */
+int32_t ppo_set_bwd_split_bf16(int32_t mode);
 /* Small minibatches (the per-GPU shard of a strong-scaling run): up to `tiles` 32-row tiles the train forward, the loss and
  * the backward-data pass of a tile run in ONE workgroup (k_policy_train_tile: nothing but the operands of the weight-
  * gradient products leaves the CU) followed by the split-K weight-gradient kernel, instead of the separate forward and

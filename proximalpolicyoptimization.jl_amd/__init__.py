@@ -111,6 +111,12 @@ def set_bwd_small_max_tiles(tiles=None):
     call("ppo_set_bwd_small_max_tiles", -1 if tiles is None else int(tiles))
 
 
+def set_bwd_split_bf16(mode=None):
+    """fp32 policies: True = the fused backward's three big products as split-fp32 ("bf16x6") products on the bf16 matrix
+    pipe, False = the pure fp32-MFMA kernel, None = default (PPO_BWD_SPLIT_BF16, else on)."""
+    call("ppo_set_bwd_split_bf16", -1 if mode is None else int(bool(mode)))
+
+
 def set_train_tile_max_tiles(tiles=None):
     """Minibatches of up to `tiles` 32-row tiles run forward + loss + backward-data of each tile in one workgroup
     (k_policy_train_tile) followed by the split-K weight-gradient kernel.  None = default, 0 = never."""

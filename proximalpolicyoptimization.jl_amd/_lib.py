@@ -86,6 +86,7 @@ SIGNATURES = {
     "ppo_rollouts_set": [H, C.c_int64, c_i8p, c_u32p, c_i32p, c_f32p, c_f32p, c_u8p],
     "ppo_forward_backward": [H, H, c_i64p, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32],
     "ppo_set_bwd_small_max_tiles": [C.c_int64],
+    "ppo_set_bwd_split_bf16": [C.c_int32],
     "ppo_set_train_tile_max_tiles": [C.c_int64],
     "ppo_set_fwd_split_max_states": [C.c_int64],
     "ppo_set_rollout_split_max_envs": [C.c_int64],

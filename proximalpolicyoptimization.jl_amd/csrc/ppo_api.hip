@@ -447,6 +447,10 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_lay
         (s = p->b2p.alloc((size_t)(NL2 > 0 ? NL2 : 1) * hidden)) ||
         (s = p->w3p.alloc((size_t)hidden * PPO_OUT)) || (s = p->b3.alloc(PPO_OUT)) || (s = p->grad.alloc(p->np + 2)) ||
         (s = p->err.alloc(1))) { delete p; return s; }
+    if (num_hidden_layers == 2 && F == 72) {             // + 4 KiB: the operand ring of the last k-steps reads ahead
+        if ((s = p->w2x.alloc((size_t)3 * hidden * hidden + 4096))) { delete p; return s; }
+        (void)hipMemsetAsync(p->w2x.p, 0, p->w2x.n * 2, g_stream);
+    }
     (void)hipMemsetAsync(p->params.p, 0, p->np * 4, g_stream);
     (void)hipMemsetAsync(p->w1p.p, 0, p->w1p.n * 4, g_stream);
     (void)hipMemsetAsync(p->w2p.p, 0, p->w2p.n * 4, g_stream);
@@ -926,8 +930,13 @@ static int64_t g_train_tile_max_tiles = [] { const char* v = std::getenv("PPO_TR
 int32_t ppo_set_train_tile_max_tiles(int64_t tiles) { g_train_tile_max_tiles = tiles < 0 ? PPO_TRAIN_TILE_DEFAULT : tiles; return PPO_OK; }
 
 // fused backward: weight-gradient products as split-fp32 ("bf16x6") MFMAs (ppo_policy_bwd_x6.hip).  PPO_BWD_SPLIT_BF16 overrides.
-static int g_bwd_split = [] { const char* v = std::getenv("PPO_BWD_SPLIT_BF16"); return v ? atoi(v) : 0; }();
+#ifndef PPO_BWD_SPLIT_DEFAULT
+#define PPO_BWD_SPLIT_DEFAULT 1
+#endif
+static int bwd_split_default() { const char* v = std::getenv("PPO_BWD_SPLIT_BF16"); return v ? (atoi(v) != 0) : PPO_BWD_SPLIT_DEFAULT; }
+static int g_bwd_split = bwd_split_default();
 int ppo_bwd_split_enabled() { return g_bwd_split; }
+int32_t ppo_set_bwd_split_bf16(int32_t mode) { g_bwd_split = mode < 0 ? bwd_split_default() : (mode != 0); return PPO_OK; }
 
 // ================================================================ training
 // B = number of 32-row tiles of the minibatch (states * H/32)

@@ -101,6 +101,9 @@ struct ppo_policy_s {
     int32_t dtype = 0;                 // PPO_DTYPE_F32 / PPO_DTYPE_BF16
     DevBuf<uint16_t> w1b, w2b, w2tb;   // [HID/32][KS][64][8] A-operand fragments of v_mfma_f32_32x32x16_bf16
     DevBuf<uint16_t> w3c, w3tb;        // layer 3 forward (compact rows 0..3) / backward ([HID][4])
+    // split-fp32 backward (ppo_policy_bwd_x6.hip): W2 as three bf16 pieces, B-operand fragments of dH1 = dZ2 W2,
+    // [in-feature tile][k-step][piece: lo, mid, hi][64 lanes][8]; L == 2, F == 72 only; rewritten by k_adam
+    DevBuf<uint16_t> w2x;
     DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
     // training workspace
     DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4: the FIRST and the LAST hidden layer

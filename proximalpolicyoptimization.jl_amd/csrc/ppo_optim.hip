@@ -113,6 +113,8 @@ struct PackPtrs {
     float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3;
     // bf16 compute mode (null in fp32 mode): A-operand fragments of v_mfma_f32_32x32x16_bf16 (ppo_policy_bf16.hip)
     uint16_t* w1b; uint16_t* w2b; uint16_t* w2tb; uint16_t* w3c; uint16_t* w3tb;
+    // split-fp32 backward (null when the policy has none): W2 as three bf16 pieces (ppo_policy_bwd_x6.hip)
+    uint16_t* w2x;
 };
 
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // RNE
@@ -156,6 +158,20 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             const bool zrow = PPO_BWD_Z2ROW_AT(HID);
             const int g = f >> 3, hh = zrow ? (f >> 2) & 1 : f & 1, e = zrow ? f & 3 : (f >> 1) & 3;   // f = 8g + 4hh + e  |  8g + 2e + hh
             P.w2tp[lo + ((size_t)((k >> 5) * (HID / 8) + g) * 64 + (k & 31) + 32 * hh) * 4 + e] = x;
+        }
+        if (P.w2x && lay == 0) {
+            // dH1[row, k] = sum_f dZ2[row, f] W[f][k]: B operand, column k, contraction f in the register order of the packed
+            // dZ2 accumulator tile; x = h + m + l, each piece the RNE bf16 of what the previous ones left (exact differences)
+            int s, hh, jj;
+            acc_kslot(f & 31, s, hh, jj);
+            const uint16_t ph = to_bf16(x);
+            const float r1 = x - __uint_as_float((uint32_t)ph << 16);
+            const uint16_t pm = to_bf16(r1);
+            const float r2 = r1 - __uint_as_float((uint32_t)pm << 16);
+            const uint16_t pl = to_bf16(r2);
+            const int KS = HID / 16;
+            uint16_t* base = P.w2x + ((size_t)(k >> 5) * KS + 2 * (f >> 5) + s) * 3 * 512 + ((size_t)(k & 31) + 32 * hh) * 8 + jj;
+            base[0] = pl; base[512] = pm; base[1024] = ph;         // [in-feature tile][k-step][piece lo, mid, hi][64 lanes][8]
         }
         if (P.w2b) {
             const uint16_t xb = to_bf16(x);
@@ -222,6 +238,7 @@ static PackPtrs packs_of(ppo_policy_s* p) {
     const bool b = (p->dtype == PPO_DTYPE_BF16);
     P.w1b = b ? p->w1b.p : nullptr; P.w2b = b ? p->w2b.p : nullptr; P.w2tb = b ? p->w2tb.p : nullptr;
     P.w3c = b ? p->w3c.p : nullptr; P.w3tb = b ? p->w3tb.p : nullptr;
+    P.w2x = p->w2x.p;
     return P;
 }
 

@@ -11,7 +11,7 @@
 // six bf16 MFMAs of k = 16 (192 clocks) stand for the eight fp32 MFMAs of k = 2 (512 clocks) that cover the same 16
 // contraction indices, with a truncation error of the order of ONE fp32 rounding -- the fp32 fma chain they replace
 // rounds once per index, this form once per MFMA.  Where one operand is exact in bf16 (the int8 state rows X) three
-// MFMAs do.  The gradient tests hold this kernel to the same 2e-5 max|g| bar against the float64 oracle as the
+// MFMAs do.  The gradient tests hold this kernel to the same 2e-5 max|g| bar against the float64 restatement of the tests as the
 // pure-fp32 kernel.
 //
 // Data flow per 32-row tile (wave w owns feature tile w of every product):
@@ -26,14 +26,15 @@
 //      operand ring instead of three).  The result has lane = feature, registers = rows: dZ1 = dH1 . lrelu'(H1) (signs
 //      by transposed reads of the H1 image) is, split in three, already the A operand of
 //   D  dW1[w,:] += dZ1^T X : 3 input tiles x 2 k-steps x 3 pieces = 18 MFMAs
-//   C  dW2[w,:] += dZ2^T H1: A = this wave's dZ2^T, recomputed lane = feature from dY, W3 and the H2^T tile (two
-//      fp32 MFMAs + 16 multiplies -- cheaper than a transpose) and split; B = the H1 piece images read transposed:
+//   C  dW2[w,:] += dZ2^T H1: A = this wave's own dZ2 fragments, each piece transposed exactly by an identity MFMA
+//      (lane = row -> lane = feature) and re-packed; B = the H1 piece images read transposed:
 //      8 k-tiles x 2 k-steps x 6 = 96 MFMAs.
 // The next tile's layer-1 / layer-2 fragments arrive by LDS-DMA during phase C into regions only this wave touches
 // and that are dead by then (its dZ2 fragment images, its H2^T rows).
 #include "ppo_internal.h"
 #include "ppo_device.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
@@ -77,42 +78,47 @@ __device__ __forceinline__ uint4 x_tr_frag(const char* p0, const char* p1) {
 }
 
 struct BwdXArgs {
+    unsigned long long* stamps;   // diagnostic build only (-DPPO_X6_STAMP): [nwg][2 waves][12 phases]
     const int8_t* states; const int32_t* idx; int64_t B;   // B = number of 32-row tiles (states * tps)
     int tps; int x_by_tile;
     const float4* act1; const float4* act2; const float4* dY;
-    const float4* w2tp; const float4* w3p;
+    const uint4* w2x; const float4* w3p;
     float* slabs; size_t slab_stride;
 };
 
 template <int F, int HID>
 struct XCfg {
     static_assert(F == 72, "state rows of 72 features (+ the ones column, zero padded to 96)");
-    static constexpr int NT = HID / 32;
-    static constexpr bool Z2R = PPO_BWD_Z2ROW_AT(HID);
-    static constexpr bool DMA1 = HID >= 256;                 // layer-1 fragments by LDS-DMA into the wave's own dZ2 slice
-    static_assert(!(DMA1 && Z2R), "the DMA landing zone is a feature-major slice");
-    static constexpr int LD = 36, RS = HID + 4;
+    static constexpr int NT = HID / 32, KS = HID / 16;       // feature tiles; k-steps of the dH1 contraction
+    static constexpr int LD = 36;
     static constexpr int WG_PER_CU = HID == 128 ? 2 : 1;
     static constexpr int XROW = 80;                          // bytes per input row of the X image (32 k-slots of bf16 + pad: 16-byte reads conflict-free)
     static constexpr int NIX = 3;                            // input tiles: 72 features, ones at 72, zeros to 96
-    static constexpr size_t oZ2 = 0, szZ2 = sizeof(float) * (Z2R ? 32 * RS : HID * LD);
-    static constexpr size_t oH2 = oZ2 + szZ2, szH2 = sizeof(float) * HID * LD;
-    static constexpr size_t oH1 = oH2 + szH2, szH1 = (size_t)3 * NT * 2048;        // [piece][feature tile][32 rows][64 B]
+    static constexpr size_t oZ2 = 0, szZ2 = (size_t)NT * 6 * 1024;                 // dZ2 fragments [feature tile][k-step 2][piece 3][64 lanes][16 B]
+    static constexpr size_t oH2 = oZ2 + szZ2, szH2 = sizeof(float) * HID * LD;      // H2^T fp32 [feature][36]
+    static constexpr size_t oH1 = oH2 + szH2, szH1 = (size_t)3 * NT * 2048;        // H1 pieces [piece][feature tile][32 rows][64 B]
     static constexpr size_t oX = oH1 + szH1, szX = (size_t)32 * NIX * XROW;
     static constexpr size_t oDY = oX + szX, oW3 = oDY + 512, oID = oW3 + (size_t)HID * 16, total = oID + 2048;
     static_assert(total <= 160 * 1024 / WG_PER_CU, "LDS budget");
 };
 
+// per-phase opaque lane id: everything lane-derived (row, half, LDS offsets) is recomputed from it where it is used, a few
+// VALU ops, instead of living in ~30 loop-invariant registers that hipcc hoists out of the tile loop and spills
+#define X6_LANE() unsigned ln = (unsigned)lane; asm volatile("" : "+v"(ln)); const int j = (int)(ln & 31u), h = (int)(ln >> 5); (void)j; (void)h
+
+#ifndef PPO_X6_RING
+#define PPO_X6_RING 6                 // W2 piece fragments in flight ahead of the dH1 chain (3 per k-step)
+#endif
+
 template <int F, int HID>
 __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
     using C = XCfg<F, HID>;
-    constexpr int NT = C::NT, NTHR = NT * 64, LD = C::LD, RS = C::RS, NIX = C::NIX, XROW = C::XROW;
-    constexpr bool Z2R = C::Z2R, DMA1 = C::DMA1;
+    constexpr int NT = C::NT, KS = C::KS, NTHR = NT * 64, LD = C::LD, NIX = C::NIX, XROW = C::XROW;
     constexpr int XQW = 32 * F / 8, XPD = (XQW + NTHR - 1) / NTHR;
-    constexpr int PF = (HID >= 256) ? 2 : 4, S4 = HID / 8;
-    static_assert(S4 % (2 * PF) == 0 && NTHR >= 256 && NTHR >= HID, "shape");
+    constexpr int RD = PPO_X6_RING;
+    static_assert(NTHR >= 256 && NTHR >= HID, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    float* const sZ2 = reinterpret_cast<float*>(smem_c + C::oZ2);
+    char* const fragZ2 = smem_c + C::oZ2;
     float* const sH2 = reinterpret_cast<float*>(smem_c + C::oH2);
     char* const imgH1 = smem_c + C::oH1;
     char* const imgX = smem_c + C::oX;
@@ -161,17 +167,16 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
     }
     __syncthreads();
 
-    const char* const w2t = reinterpret_cast<const char*>(a.w2tp + (size_t)w * S4 * 64);   // this wave's W2^T tile (scalar base)
-    const unsigned lo16 = (unsigned)lane * 16u;
-    const unsigned fb = (unsigned)(32 * w + 4 * h);
+    // this wave's W2 piece stream: [k-step][piece: lo, mid, hi][64 lanes][8 bf16], 3 KS KiB back to back
+    const char* const wx = reinterpret_cast<const char*>(a.w2x + (size_t)w * 3 * KS * 64);
     float* const h2slice = sH2 + (size_t)(32 * w) * LD;
-    float* const z2slice = sZ2 + (size_t)(32 * w) * LD;             // DMA1 only (feature-major dZ2: rows [32w, 32w+32) are this wave's)
+    char* const z2own = fragZ2 + (size_t)w * 6 * 1024;              // this wave's dZ2 fragments; DMA landing zone of the next tile's layer-1 fragments
     const unsigned h2slice_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)h2slice);
-    const unsigned z2slice_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)z2slice);
-    // LDS-DMA of a tile's fragments (4 x 1 KiB, lane-linear) into a slice that only this wave touches; issued from inline
+    const unsigned z2own_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)z2own);
+    // LDS-DMA of a tile's fragments (4 x 1 KiB, lane-linear) into a region that only this wave touches; issued from inline
     // asm and waited for with an explicit vmcnt(0) in phase A (see ppo_policy_bwd.hip for why hipcc must not know)
-    auto dma_frag = [&](const float4* base, int64_t t, unsigned dst_lds) {
-        const float4* src = base + ((size_t)t * NT + w) * 4 * 64 + lane;
+    auto dma_frag = [&](const float4* base, int64_t t, unsigned dst_lds, unsigned ln) {
+        const float4* src = base + ((size_t)t * NT + w) * 4 * 64 + ln;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned keep;
@@ -181,93 +186,100 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                          : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
         }
     };
-    float4 v1[4], dy;
+    float4 dy;
     uint2 xd[XPD];
-    auto issue_tile_loads = [&](int64_t t, int sidx) {
-        if constexpr (!DMA1) {
-            const char* s1 = reinterpret_cast<const char*>(a.act1 + ((size_t)t * NT + w) * 4 * 64);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                typedef float f32x4l __attribute__((ext_vector_type(4)));
-                const f32x4l t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4l*>(s1 + (lo16 + (unsigned)q * 1024u)));
-                v1[q] = make_float4(t4.x, t4.y, t4.z, t4.w);
-            }
-        }
-        dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (unsigned)j * 16u);
+    auto issue_tile_loads = [&](int64_t t, int sidx, unsigned ln) {
+        dy = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.dY + (size_t)t * 32) + (ln & 31u) * 16u);
         const char* xs = reinterpret_cast<const char*>(a.states + (a.x_by_tile ? (size_t)t : ((size_t)sidx * a.tps + (size_t)(t % a.tps))) * 32 * F);
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const unsigned u = (unsigned)tid + (unsigned)i * NTHR;
+            const unsigned u = (unsigned)(64 * w) + ln + (unsigned)i * NTHR;
             const unsigned d = (u & 31u) * (unsigned)(F / 8) + (u >> 5);      // lane -> row, 32-lane group -> one 8-feature unit
             xd[i] = u < (unsigned)XQW ? *reinterpret_cast<const uint2*>(xs + d * 8u) : make_uint2(0u, 0u);
         }
     };
     if ((int64_t)blockIdx.x < a.B) {
-        dma_frag(a.act2, blockIdx.x, h2slice_lds);
-        if constexpr (DMA1) dma_frag(a.act1, blockIdx.x, z2slice_lds);
-        issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
+        dma_frag(a.act2, blockIdx.x, h2slice_lds, (unsigned)lane);
+        dma_frag(a.act1, blockIdx.x, z2own_lds, (unsigned)lane);
+        issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]), (unsigned)lane);
     }
 
+#ifdef PPO_X6_STAMP
+    unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#define XSTAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define XSTAMP(i) do {} while (0)
+#endif
     for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
-        unsigned lb = fb * LD + j;
-        asm volatile("" : "+v"(lb));                               // per-tile opaque base: nothing derived from it is hoisted and spilled
-        float* const z2b = sZ2 + lb;
-        float* const h2b = sH2 + lb;
-        // this lane's 8-byte chunks in the H1 piece images of feature tile w: row j, chunk (2q + h) ^ ((j >> 2) & 7)
-        unsigned hw = (unsigned)(w * 2048 + 64 * j);
-        asm volatile("" : "+v"(hw));
-        const unsigned cx = (unsigned)(j >> 2) & 7u;
         // ================= phase A: stage the tile
-        float4 v2[4];
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // everything this wave has in flight (DMAs included)
-            if constexpr (DMA1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // everything this wave has in flight (the DMAs included)
+        {   // H1 (lane = row j, register 4q+e <-> feature e + 8q + 4h of tile w) -> three bf16 pieces -> images
+            X6_LANE();
+            // this lane's 8-byte chunks in the H1 piece images of feature tile w: row j, chunk (2q + h) ^ ((j >> 2) & 7)
+            const unsigned hw = (unsigned)(w * 2048 + 64 * j), cx = (unsigned)(j >> 2) & 7u;
+            float4 v1[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v1[q] = *reinterpret_cast<const float4*>(z2slice + q * 256 + lane * 4);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v2[q] = *reinterpret_cast<const float4*>(h2slice + q * 256 + lane * 4);
+            for (int q = 0; q < 4; ++q) v1[q] = *reinterpret_cast<const float4*>(z2own + q * 1024 + ln * 16);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        // H1 (lane = row j, register 4q+e <-> feature e + 8q + 4h of tile w) -> three bf16 pieces -> images
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float hv[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
-            uint2 ph, pm, pl;
-            x_split4(hv, ph, pm, pl);
-            const unsigned off = hw + 8u * (((unsigned)(2 * q + h)) ^ cx);
-            *reinterpret_cast<uint2*>(imgH1 + off) = ph;
-            *reinterpret_cast<uint2*>(imgH1 + NT * 2048 + off) = pm;
-            *reinterpret_cast<uint2*>(imgH1 + 2 * NT * 2048 + off) = pl;
+            for (int q = 0; q < 4; ++q) {
+                const float hv[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+                uint2 ph, pm, pl;
+                x_split4(hv, ph, pm, pl);
+                const unsigned off = hw + 8u * (((unsigned)(2 * q + h)) ^ cx);
+                *reinterpret_cast<uint2*>(imgH1 + off) = ph;
+                *reinterpret_cast<uint2*>(imgH1 + NT * 2048 + off) = pm;
+                *reinterpret_cast<uint2*>(imgH1 + 2 * NT * 2048 + off) = pl;
+            }
         }
-        if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+        __builtin_amdgcn_sched_barrier(0);                          // (keeps the two halves of the phase from sharing registers)
+        XSTAMP(0);
         {
+            X6_LANE();
+            float* const h2b = sH2 + (32 * w + 4 * h) * LD + j;
+            const float w3a0 = sW3[(32 * w + j) * 4 + h], w3a1 = sW3[(32 * w + j) * 4 + 2 + h];
+            float4 v2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v2[q] = *reinterpret_cast<const float4*>(h2slice + q * 256 + ln * 4);
+            if (w == 0 && h == 0) *reinterpret_cast<float4*>(&sDY[j * 4]) = dy;
+            // dZ2 (lane = row): dH2^T[f, row] = sum_o W3[o, f] dY[row, o] as two fp32 MFMAs (k = the 4 outputs)
             f32x16 dh2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dh2[r] = 0.0f;
-            const float w3a0 = sW3[(32 * w + j) * 4 + h], w3a1 = sW3[(32 * w + j) * 4 + 2 + h];
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a0, h ? dy.y : dy.x, dh2, 0, 0, 0);
             dh2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3a1, h ? dy.w : dy.z, dh2, 0, 0, 0);
-            float* const z2r = sZ2 + j * RS + fb;                      // Z2R: this lane's row, features 32w + 4h + 8q .. +3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the raw fragments are in registers: the slice may be overwritten
+            // registers 8s .. 8s+7 packed = the A-operand fragment of k-step (w, s) of dH1 = dZ2 W2 (k order: the
+            // accumulator-register order, acc_kslot in ppo_optim.hip)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
-                float z[4];
+            for (int s = 0; s < 2; ++s) {
+                uint2 zh[2], zm[2], zl[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int fo = e + 8 * q;
-                    z[e] = dh2[4 * q + e] * (h2v[e] > 0.0f ? 1.0f : 0.01f);
-                    if constexpr (!Z2R) z2b[fo * LD] = z[e];
-                    h2b[fo * LD] = h2v[e];
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * s + qq;
+                    const float h2v[4] = {v2[q].x, v2[q].y, v2[q].z, v2[q].w};
+                    float z[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        z[e] = dh2[4 * q + e] * (h2v[e] > 0.0f ? 1.0f : 0.01f);
+                        h2b[(e + 8 * q) * LD] = h2v[e];
+                    }
+                    x_split4(z, zh[qq], zm[qq], zl[qq]);
                 }
-                if constexpr (Z2R) *reinterpret_cast<float4*>(z2r + 8 * q) = make_float4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<uint4*>(z2own + (s * 3 + 0) * 1024 + ln * 16) = make_uint4(zh[0].x, zh[0].y, zh[1].x, zh[1].y);
+                *reinterpret_cast<uint4*>(z2own + (s * 3 + 1) * 1024 + ln * 16) = make_uint4(zm[0].x, zm[0].y, zm[1].x, zm[1].y);
+                *reinterpret_cast<uint4*>(z2own + (s * 3 + 2) * 1024 + ln * 16) = make_uint4(zl[0].x, zl[0].y, zl[1].x, zl[1].y);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        XSTAMP(1);
         // state rows -> bf16 X image [input][k-slot]; tile row R sits in k-slot R with bits 2 and 3 swapped (the row order
-        // the identity-MFMA transpose of dZ1 leaves in phase D's A operands)
+        // of accumulator registers: phase D's A operands are the dH1 accumulators)
+        {
+        X6_LANE();
 #pragma unroll
         for (int i = 0; i < XPD; ++i) {
-            const int d = tid + i * NTHR;
+            const int d = 64 * w + (int)ln + i * NTHR;
             if (d < XQW) {
                 const int row = d & 31, c = d >> 5;
                 const int slot = (row & 19) | ((row & 4) << 1) | ((row & 8) >> 1);
@@ -280,9 +292,13 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 }
             }
         }
+        }
+        XSTAMP(2);
         __syncthreads();
-        // ================= phase B: small VALU grads, dH1 = W2^T dZ2 (fp32 MFMA), dZ1, transposed, dW1
+        XSTAMP(3);
+        // ================= phase B: small VALU grads, dH1 = dZ2 W2, dZ1, dW1
         auto small_grads = [&]() {
+            X6_LANE();
             const float* gh = sH2 + (32 * w + j) * LD + 16 * h;
             const float* gy = sDY + 64 * h;
             pk2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
@@ -302,167 +318,196 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             dw3[0] += d01.x; dw3[1] += d01.y; dw3[2] += d23.x; dw3[3] += d23.y;
-            if (tid < 4) {
+            if (w == 0 && ln < 4u) {
                 float s = 0.f;
-                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + tid];
+                for (int r = 0; r < 32; ++r) s += sDY[r * 4 + ln];
                 db3 += s;
             }
         };
-        float4 ringA[PF], ringB[PF];
+        uint4 ring[RD];
 #pragma unroll
-        for (int g = 0; g < PF; ++g) ringA[g] = *reinterpret_cast<const float4*>(w2t + (lo16 + (unsigned)g * 1024u));
+        for (int g = 0; g < RD; ++g) { unsigned lo = (unsigned)lane * 16u; asm volatile("" : "+v"(lo)); ring[g] = *reinterpret_cast<const uint4*>(wx + (lo + (unsigned)g * 1024u)); }
         const bool grads_first = (2 * w < NT);
         const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;
         if (grads_first) small_grads();
+        XSTAMP(4);
         {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float* bz = Z2R ? sZ2 + j * RS + 4 * h : sZ2 + h * LD + j;
-            const char* wn = w2t + (size_t)PF * 1024;
-            auto mfma_set = [&](const float4 (&rg)[PF]) {
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    float b[4];
-                    if constexpr (Z2R) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(bz + 8 * u);
-                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) b[e] = bz[(8 * u + 2 * e) * LD];
-                    }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].x, b[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].y, b[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].z, b[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[u].w, b[3], acc, 0, 0, 0);
-                }
-                bz += Z2R ? 8 * PF : 8 * PF * LD;
-            };
+            // one pass over the k-steps; per k-step the three W2 pieces (lo, mid, hi: 1 + 2 + 3 MFMAs against the dZ2 pieces).
+            // The stream pointer is a scalar that advances 1 KiB per piece, the fragment pointer advances per ring round:
+            // nothing here is a per-step address the compiler could hoist out of the tile loop and spill
+            const char* wn = wx + (size_t)RD * 1024;
+            static_assert(RD % 3 == 0 && KS % (RD / 3) == 0, "ring rounds");
+            unsigned zo = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(zo));
+            const char* zp = fragZ2 + zo;
+            const unsigned lo16 = zo;
 #pragma unroll 1
-            for (int s0 = 0; s0 < S4; s0 += 2 * PF) {
+            for (int k0 = 0; k0 < KS; k0 += RD / 3) {
 #pragma unroll
-                for (int u = 0; u < PF; ++u) ringB[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));
-                wn += (size_t)PF * 1024;
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_set(ringA);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < PF; ++u) ringA[u] = *reinterpret_cast<const float4*>(wn + (lo16 + (unsigned)u * 1024u));   // tail padding covers the over-read
-                wn += (size_t)PF * 1024;
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_set(ringB);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < RD / 3; ++u) {
+                    const uint4 z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
+                    const uint4 z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
+                    const uint4 z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
+                    acc = x_mfma(z_h, ring[3 * u + 0], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = x_mfma(z_m, ring[3 * u + 1], acc);
+                    acc = x_mfma(z_h, ring[3 * u + 1], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = x_mfma(z_l, ring[3 * u + 2], acc);
+                    acc = x_mfma(z_m, ring[3 * u + 2], acc);
+                    acc = x_mfma(z_h, ring[3 * u + 2], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    wn += 3 * 1024;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                zp += (RD / 3) * 3 * 1024;
             }
-            // dZ1 = dH1 . lrelu'(H1): the sign of H1 from the first piece of its image (this wave's own tile, row j)
+            XSTAMP(5);
+            // acc: dH1, lane = feature 32w + j, register r <-> tile row (r&3) + 8(r>>2) + 4h.  dZ1 = dH1 . lrelu'(H1): the sign
+            // of H1 from the first piece of its image, read transposed (block rows 8g + 4h .. +3 = registers 4g .. 4g+3)
+            X6_LANE();
+            const unsigned q4 = (ln & 15u) >> 2, p4 = ln & 3u, g1 = (ln >> 4) & 1u;
+            typedef __attribute__((address_space(3))) xs16x4 lds_s16x4;
             uint2 zh[4], zm[4], zl[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint2 hp = *reinterpret_cast<const uint2*>(imgH1 + hw + 8u * (((unsigned)(2 * q + h)) ^ cx));
-                const float z1[4] = {acc[4 * q + 0] * ((int16_t)(hp.x & 0xFFFFu) > 0 ? 1.0f : 0.01f),
-                                     acc[4 * q + 1] * ((int32_t)hp.x >= 0x10000 ? 1.0f : 0.01f),
-                                     acc[4 * q + 2] * ((int16_t)(hp.y & 0xFFFFu) > 0 ? 1.0f : 0.01f),
-                                     acc[4 * q + 3] * ((int32_t)hp.y >= 0x10000 ? 1.0f : 0.01f)};
-                x_split4(z1, zh[q], zm[q], zl[q]);
+            for (int g = 0; g < 4; ++g) {
+                const unsigned r0 = 8u * g + 4u * h;
+                const char* hp = imgH1 + w * 2048 + 64u * (r0 + q4) + 8u * ((4u * g1 + p4) ^ ((r0 >> 2) & 7u));
+                const uint2 sg = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hp)));
+                const float z1[4] = {acc[4 * g + 0] * ((int16_t)(sg.x & 0xFFFFu) > 0 ? 1.0f : 0.01f),
+                                     acc[4 * g + 1] * ((int32_t)sg.x >= 0x10000 ? 1.0f : 0.01f),
+                                     acc[4 * g + 2] * ((int16_t)(sg.y & 0xFFFFu) > 0 ? 1.0f : 0.01f),
+                                     acc[4 * g + 3] * ((int32_t)sg.y >= 0x10000 ? 1.0f : 0.01f)};
+                x_split4(z1, zh[g], zm[g], zl[g]);
             }
             // ================= phase D: dW1[k,i] += sum_rows dZ1[k,row] * X[i,row]   (wave w: k-tile w; input 72 = ones: db1)
-            const uint4 id0 = sID[lane], id1 = sID[64 + lane];
             const char* const xb = imgX + j * XROW + 16 * h;           // k-slots 16s + 8h .. +7 of input 32 it + j
 #pragma unroll
-            for (int p = 2; p >= 0; --p) {                              // smallest piece first
-                const uint2* zp = p == 0 ? zh : (p == 1 ? zm : zl);
-                f32x16 t;
+            for (int s = 0; s < 2; ++s) {
+                uint4 bx[NIX];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = 0.0f;
-                t = x_mfma(make_uint4(zp[0].x, zp[0].y, zp[1].x, zp[1].y), id0, t);
-                t = x_mfma(make_uint4(zp[2].x, zp[2].y, zp[3].x, zp[3].y), id1, t);
-                // lane (feature 32w + j, half h), register r: dZ1 piece of tile row (r&3) + 8(r>>2) + 4h, an exact bf16 value
+                for (int it = 0; it < NIX; ++it) bx[it] = *reinterpret_cast<const uint4*>(xb + 32 * it * XROW + 32 * s);
+                const uint4 a_l = make_uint4(zl[2 * s].x, zl[2 * s].y, zl[2 * s + 1].x, zl[2 * s + 1].y);
+                const uint4 a_m = make_uint4(zm[2 * s].x, zm[2 * s].y, zm[2 * s + 1].x, zm[2 * s + 1].y);
+                const uint4 a_h = make_uint4(zh[2 * s].x, zh[2 * s].y, zh[2 * s + 1].x, zh[2 * s + 1].y);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const uint4 af = make_uint4(x_perm(t[8 * s + 0], t[8 * s + 1]), x_perm(t[8 * s + 2], t[8 * s + 3]),
-                                                x_perm(t[8 * s + 4], t[8 * s + 5]), x_perm(t[8 * s + 6], t[8 * s + 7]));
-#pragma unroll
-                    for (int it = 0; it < NIX; ++it) {
-                        const uint4 bx = *reinterpret_cast<const uint4*>(xb + 32 * it * XROW + 32 * s);
-                        accW1[it] = x_mfma(af, bx, accW1[it]);
-                    }
+                for (int it = 0; it < NIX; ++it) {
+                    accW1[it] = x_mfma(a_l, bx[it], accW1[it]);
+                    accW1[it] = x_mfma(a_m, bx[it], accW1[it]);
+                    accW1[it] = x_mfma(a_h, bx[it], accW1[it]);
                 }
             }
         }
+        XSTAMP(6);
         if (!grads_first) small_grads();
-        // every wave is through with the whole dZ2 tile (B operands of the chain) and with its own H2 rows: the slices
-        // become DMA landing zones below
+        XSTAMP(7);
+        // every wave is through with the dZ2 fragments (A operands of the chain) and with its own H2^T rows' dW3 sums
         __syncthreads();
+        XSTAMP(8);
         // ================= phase C: dW2[f,k] += sum_rows dZ2[f,row] * H1[k,row]   (wave w: f-tile w)
         {
-            // A operand: rows 16s + 8h .. +7 of this lane's feature 32w + j, fp32 from the dZ2 tile, split here
+            // A operand: dZ2^T of this wave's features with lane = feature.  The pieces sit in LDS as this wave's own fragments
+            // (lane = row, written in phase A): an IDENTITY MFMA transposes each piece exactly (D = P I: lane (feature, h) gets
+            // rows (r&3) + 8(r>>2) + 4h of the packed tile in register r, every value one bf16 number), v_perm packs them
+            // again.  6 MFMAs + 24 packs instead of recomputing dZ2 in the other orientation and splitting it a second time.
+            X6_LANE();
             uint4 ah[2], am[2], al[2];
-            float s2 = 0.f;
+            {
+                const uint4 id0 = sID[ln], id1 = sID[64 + ln];
+                float s2 = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float zv[8];
-                if constexpr (Z2R) {
-                    const float* pa = sZ2 + (16 * s + 8 * h) * RS + 32 * w + j;
+                for (int p = 2; p >= 0; --p) {                          // smallest piece first (db2 = the sum over the 32 rows)
+                    const uint4 f0 = *reinterpret_cast<const uint4*>(z2own + (0 * 3 + p) * 1024 + ln * 16);
+                    const uint4 f1 = *reinterpret_cast<const uint4*>(z2own + (1 * 3 + p) * 1024 + ln * 16);
+                    f32x16 t;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) zv[e] = pa[e * RS];
-                } else {
-                    const float* pa = sZ2 + (32 * w + j) * LD + 16 * s + 8 * h;
-                    const float4 z0 = *reinterpret_cast<const float4*>(pa), z1 = *reinterpret_cast<const float4*>(pa + 4);
-                    zv[0] = z0.x; zv[1] = z0.y; zv[2] = z0.z; zv[3] = z0.w; zv[4] = z1.x; zv[5] = z1.y; zv[6] = z1.z; zv[7] = z1.w;
+                    for (int r = 0; r < 16; ++r) t[r] = 0.0f;
+                    t = x_mfma(f0, id0, t);
+                    t = x_mfma(f1, id1, t);
+                    float sp = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sp += t[r];
+                    s2 += sp;
+                    uint4 pk[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        pk[s] = make_uint4(x_perm(t[8 * s + 0], t[8 * s + 1]), x_perm(t[8 * s + 2], t[8 * s + 3]),
+                                           x_perm(t[8 * s + 4], t[8 * s + 5]), x_perm(t[8 * s + 6], t[8 * s + 7]));
+                    if (p == 0) { ah[0] = pk[0]; ah[1] = pk[1]; } else if (p == 1) { am[0] = pk[0]; am[1] = pk[1]; } else { al[0] = pk[0]; al[1] = pk[1]; }
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s2 += zv[e];
-                const float lo4[4] = {zv[0], zv[1], zv[2], zv[3]}, hi4[4] = {zv[4], zv[5], zv[6], zv[7]};
-                uint2 p0, m0, l0, p1, m1, l1;
-                x_split4(lo4, p0, m0, l0);
-                x_split4(hi4, p1, m1, l1);
-                ah[s] = make_uint4(p0.x, p0.y, p1.x, p1.y); am[s] = make_uint4(m0.x, m0.y, m1.x, m1.y); al[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                db2 += s2;
             }
-            db2 += s2;
-            // the next tile's inputs: fragments by LDS-DMA into the (now idle) slices, dY and the state dwords into registers
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of its slices have returned
-            dma_frag(a.act2, ntile, h2slice_lds);
-            if constexpr (DMA1) dma_frag(a.act1, ntile, z2slice_lds);
+            // the next tile's inputs: fragments by LDS-DMA into the (now idle) regions, dY and the state dwords into registers
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of its H2^T rows have returned
+            dma_frag(a.act2, ntile, h2slice_lds, ln);
+            dma_frag(a.act1, ntile, z2own_lds, ln);
             {
                 int nidx = 0;
                 if (!a.x_by_tile) {
                     const int32_t* ip = a.idx + ntile / a.tps;
                     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(nidx) : "s"(ip) : "memory");
                 }
-                issue_tile_loads(ntile, nidx);
+                issue_tile_loads(ntile, nidx, ln);
             }
-            // B operands: H1 pieces of k-tile kt, transposed reads.  16-lane group G = lane >> 4 takes columns 16(G&1) ..
-            // of rows r0 .. r0+3, r0 = 16s + 8h + 4u; lane 4q + p of the group addresses row r0 + q, 8-byte chunk 4(G&1) + p
+            // B operands: H1 pieces of k-tile kt, transposed reads.  k-slot (s, h, e) <-> tile row 16s + 8(e>>2) + 4h + (e&3): the
+            // two block reads of a fragment take rows r0 .. r0+3, r0 = 16s + 8u + 4h; 16-lane group G = lane >> 4 takes columns
+            // 16(G&1) .., its lane 4q + p addresses row r0 + q, 8-byte chunk 4(G&1) + p
             unsigned tb[2][2];
             {
-                const unsigned q4 = ((unsigned)lane & 15u) >> 2, p4 = (unsigned)lane & 3u, g1 = ((unsigned)lane >> 4) & 1u;
+                const unsigned q4 = (ln & 15u) >> 2, p4 = ln & 3u, g1 = (ln >> 4) & 1u;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const unsigned r0 = 16u * s + 8u * h + 4u * u;
+                        const unsigned r0 = 16u * s + 8u * u + 4u * h;
                         tb[s][u] = 64u * (r0 + q4) + 8u * ((4u * g1 + p4) ^ ((r0 >> 2) & 7u));
                     }
                 asm volatile("" : "+v"(tb[0][0]), "+v"(tb[0][1]), "+v"(tb[1][0]), "+v"(tb[1][1]));
             }
+            // one fragment set (k-tile kt, k-step s) of lookahead: its six transposed reads are issued before the six MFMAs
+            // of the set in front of it (pinned: left alone hipcc hoists every read of the unrolled loop and spills)
+            auto load_b = [&](int g, uint4 (&b)[3]) {
+                const char* i0 = imgH1 + (g >> 1) * 2048;
+                const int s = g & 1;
+                b[0] = x_tr_frag(i0 + tb[s][0], i0 + tb[s][1]);
+                b[1] = x_tr_frag(i0 + NT * 2048 + tb[s][0], i0 + NT * 2048 + tb[s][1]);
+                b[2] = x_tr_frag(i0 + 2 * NT * 2048 + tb[s][0], i0 + 2 * NT * 2048 + tb[s][1]);
+            };
+            XSTAMP(9);
+            uint4 bc[3], bn[3];
+            load_b(0, bc);
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
+            for (int g = 0; g < 2 * NT; ++g) {
+                const int kt = g >> 1, s = g & 1;
+                if (g + 1 < 2 * NT) load_b(g + 1, bn);
+                __builtin_amdgcn_sched_barrier(0);
+                accW2[kt] = x_mfma(al[s], bc[0], accW2[kt]);
+                accW2[kt] = x_mfma(am[s], bc[1], accW2[kt]);
+                accW2[kt] = x_mfma(ah[s], bc[2], accW2[kt]);
+                accW2[kt] = x_mfma(am[s], bc[0], accW2[kt]);
+                accW2[kt] = x_mfma(ah[s], bc[1], accW2[kt]);
+                accW2[kt] = x_mfma(ah[s], bc[0], accW2[kt]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const char* i0 = imgH1 + kt * 2048;
-                    const uint4 bh = x_tr_frag(i0 + tb[s][0], i0 + tb[s][1]);
-                    const uint4 bm = x_tr_frag(i0 + NT * 2048 + tb[s][0], i0 + NT * 2048 + tb[s][1]);
-                    const uint4 bl = x_tr_frag(i0 + 2 * NT * 2048 + tb[s][0], i0 + 2 * NT * 2048 + tb[s][1]);
-                    accW2[kt] = x_mfma(al[s], bh, accW2[kt]);
-                    accW2[kt] = x_mfma(am[s], bm, accW2[kt]);
-                    accW2[kt] = x_mfma(ah[s], bl, accW2[kt]);
-                    accW2[kt] = x_mfma(am[s], bh, accW2[kt]);
-                    accW2[kt] = x_mfma(ah[s], bm, accW2[kt]);
-                    accW2[kt] = x_mfma(ah[s], bh, accW2[kt]);
-                }
+                for (int p = 0; p < 3; ++p) bc[p] = bn[p];
             }
         }
+        XSTAMP(10);
         __syncthreads();
+        XSTAMP(11);
     }
+#ifdef PPO_X6_STAMP
+    if (a.stamps && lane == 0 && (w == 0 || w == NT - 1))
+        for (int i = 0; i < 12; ++i) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 12 + i] = st_sum[i];
+#endif
 
     // ================= write the slab (fragment order; k_grad_reduce maps it to Flux order)
     constexpr int FP = 96, NI = FP / 32;
@@ -499,13 +544,27 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
     if (tid < 4) sb3[tid] = db3;
 }
 
+#ifdef PPO_X6_STAMP
+static unsigned long long* g_x6_stamps = nullptr;
+extern "C" int32_t ppo_debug_x6_stamps(unsigned long long* out) {
+    if (!g_x6_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_x6_stamps, 512 * 24 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int32_t launch_policy_bwd_x6(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B) {
     BwdXArgs a;
+    a.stamps = nullptr;
+#ifdef PPO_X6_STAMP
+    { if (!g_x6_stamps) (void)hipMalloc((void**)&g_x6_stamps, 512 * 24 * 8); a.stamps = g_x6_stamps; }
+#endif
     a.tps = ro->H / 32;
     a.states = ro->compact ? p->xs.p : ro->states.p; a.x_by_tile = ro->compact ? 1 : 0;
     a.idx = idx_dev; a.B = B * a.tps;
     a.act1 = (const float4*)p->act1.p; a.act2 = (const float4*)p->act2.p; a.dY = (const float4*)p->dY.p;
-    a.w2tp = (const float4*)p->w2tp.p; a.w3p = (const float4*)p->w3p.p;
+    if (p->L != 2 || !p->w2x.p) return PPO_ERR_UNSUPPORTED;
+    a.w2x = (const uint4*)p->w2x.p; a.w3p = (const float4*)p->w3p.p;
     a.slabs = p->slabs.p; a.slab_stride = slab_floats(p->F, p->HID);
     int nwg = 0;
     ProfScope ps("k_policy_bwd");

@@ -377,19 +377,23 @@ def storage_mode(request, P):
     P.set_rollout_compact(None)
 
 
-@pytest.fixture(params=[0, 4096, -1], ids=["large-batch-kernels", "small-batch-kernels", "train-tile-kernels"])
+@pytest.fixture(params=[0, -2, 4096, -1], ids=["large-batch-kernels", "large-batch-fp32-mfma", "small-batch-kernels", "train-tile-kernels"])
 def bwd_form(request, P):
-    """All three kernel sets at test sizes: the fused backward + one-wave-per-state train forward (forced); the three-product
+    """All kernel sets at test sizes: the fused backward (its products as split-fp32 MFMAs on the bf16 pipe: the default;
+    and as pure fp32 MFMAs: ppo_set_bwd_split_bf16(0)) + one-wave-per-state train forward (forced); the three-product
     backward and the 2 / 4-waves-per-state train forward (ppo_set_bwd_small_max_tiles, ppo_set_fwd_split_max_states); and
     the one-workgroup-per-tile training pass + operand-layout weight-gradient kernel (ppo_set_train_tile_max_tiles; it
     covers Q = 8 states in the expanded storage form and falls back to the others elsewhere)."""
-    if request.param < 0:
+    if request.param == -1:
         P.set_train_tile_max_tiles(1 << 20)
     else:
         P.set_train_tile_max_tiles(0)
-        P.set_bwd_small_max_tiles(request.param)
-        P.set_fwd_split_max_states(min(request.param, 512))
+        P.set_bwd_small_max_tiles(max(request.param, 0))
+        P.set_fwd_split_max_states(min(max(request.param, 0), 512))
+        if request.param == -2:
+            P.set_bwd_split_bf16(False)
     yield request.param
+    P.set_bwd_split_bf16(None)
     P.set_bwd_small_max_tiles(None)
     P.set_fwd_split_max_states(None)
     P.set_train_tile_max_tiles(None)
