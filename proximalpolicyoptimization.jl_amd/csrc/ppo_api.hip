@@ -450,6 +450,9 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_lay
     if (num_hidden_layers == 2 && F == 72) {             // + 4 KiB: the operand ring of the last k-steps reads ahead
         if ((s = p->w2x.alloc((size_t)3 * hidden * hidden + 4096))) { delete p; return s; }
         (void)hipMemsetAsync(p->w2x.p, 0, p->w2x.n * 2, g_stream);
+        if ((s = p->w2fx.alloc((size_t)3 * hidden * hidden + 4096)) || (s = p->w1x.alloc((size_t)(hidden / 32) * 5 * 3 * 512 + 4096))) { delete p; return s; }
+        (void)hipMemsetAsync(p->w2fx.p, 0, p->w2fx.n * 2, g_stream);
+        (void)hipMemsetAsync(p->w1x.p, 0, p->w1x.n * 2, g_stream);       // inputs 72 .. 79 of the last k-step stay zero
     }
     (void)hipMemsetAsync(p->params.p, 0, p->np * 4, g_stream);
     (void)hipMemsetAsync(p->w1p.p, 0, p->w1p.n * 4, g_stream);

@@ -104,6 +104,9 @@ struct ppo_policy_s {
     // split-fp32 backward (ppo_policy_bwd_x6.hip): W2 as three bf16 pieces, B-operand fragments of dH1 = dZ2 W2,
     // [in-feature tile][k-step][piece: lo, mid, hi][64 lanes][8]; L == 2, F == 72 only; rewritten by k_adam
     DevBuf<uint16_t> w2x;
+    // split-fp32 train forward (ppo_policy_fwd_x6.hip): A-operand piece fragments [feature tile][k-step][piece][64][8] of
+    // layer 1 (5 k-steps of natural input order, zero padded from 72 to 80) and layer 2 (k order of packed accumulators)
+    DevBuf<uint16_t> w1x, w2fx;
     DevBuf<float> grad;                // [np + 2]  (+ ppo sum, entropy sum)
     // training workspace
     DevBuf<float> act1, act2;          // saved activations, D-fragment order [tiles][HID/32][4][64] float4: the FIRST and the LAST hidden layer
@@ -243,6 +246,8 @@ struct FwdArgs;
 int32_t launch_rollout_split(ppo_policy_s* p, FwdArgs& a, int64_t N, int tps, int V, int env);
 // train forward with 2 or 4 waves per state for small minibatches (ppo_policy_fwd_split.hip)
 int32_t launch_policy_train_fwd_split(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact);
+// train forward with its Dense products as split-fp32 MFMAs (ppo_policy_fwd_x6.hip); PPO_ERR_UNSUPPORTED: not covered / switched off
+int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact);
 int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t B, int tps);
 int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& args, int64_t N, int tps, int V);
 int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);

@@ -114,10 +114,18 @@ struct PackPtrs {
     // bf16 compute mode (null in fp32 mode): A-operand fragments of v_mfma_f32_32x32x16_bf16 (ppo_policy_bf16.hip)
     uint16_t* w1b; uint16_t* w2b; uint16_t* w2tb; uint16_t* w3c; uint16_t* w3tb;
     // split-fp32 backward (null when the policy has none): W2 as three bf16 pieces (ppo_policy_bwd_x6.hip)
-    uint16_t* w2x;
+    uint16_t* w2x; uint16_t* w1x; uint16_t* w2fx;
 };
 
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // RNE
+// x = h + m + l: each piece the RNE bf16 of what the previous ones left (the differences are exact in fp32)
+__device__ __forceinline__ void split3_bf16(float x, uint16_t& ph, uint16_t& pm, uint16_t& pl) {
+    ph = to_bf16(x);
+    const float r1 = x - __uint_as_float((uint32_t)ph << 16);
+    pm = to_bf16(r1);
+    const float r2 = r1 - __uint_as_float((uint32_t)pm << 16);
+    pl = to_bf16(r2);
+}
 // k-slot of contraction index kk (0..31) inside a 32-wide tile when the other operand is a packed accumulator tile:
 // k-step s = kk>>4, lane half hh and element jj such that 16s + 8(jj>>2) + 4hh + (jj&3) == kk
 __device__ __forceinline__ void acc_kslot(int kk, int& s, int& hh, int& jj) {
@@ -131,6 +139,12 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
         const int io = (int)(i % HID), k = (int)(i / HID);
         const int hh = k / (F / 2), s = k % (F / 2);
         P.w1p[((size_t)((io >> 5) * (F / 8) + (s >> 2)) * 64 + (io & 31) + 32 * hh) * 4 + (s & 3)] = x;
+        if (P.w1x) {                                     // split-fp32 train forward: natural k order, 5 k-steps, three pieces
+            uint16_t ph, pm, pl;
+            split3_bf16(x, ph, pm, pl);
+            uint16_t* base = P.w1x + ((size_t)(io >> 5) * 5 + (k >> 4)) * 3 * 512 + ((size_t)(io & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+            base[0] = pl; base[512] = pm; base[1024] = ph;
+        }
         if (P.w1b) {                                     // natural k order: k = 16*step + 8*half + element
             const int KS1 = (F + 15) / 16;
             P.w1b[((size_t)((io >> 5) * KS1 + (k >> 4)) * 64 + (io & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)] = to_bf16(x);
@@ -160,18 +174,22 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
             P.w2tp[lo + ((size_t)((k >> 5) * (HID / 8) + g) * 64 + (k & 31) + 32 * hh) * 4 + e] = x;
         }
         if (P.w2x && lay == 0) {
-            // dH1[row, k] = sum_f dZ2[row, f] W[f][k]: B operand, column k, contraction f in the register order of the packed
-            // dZ2 accumulator tile; x = h + m + l, each piece the RNE bf16 of what the previous ones left (exact differences)
-            int s, hh, jj;
-            acc_kslot(f & 31, s, hh, jj);
-            const uint16_t ph = to_bf16(x);
-            const float r1 = x - __uint_as_float((uint32_t)ph << 16);
-            const uint16_t pm = to_bf16(r1);
-            const float r2 = r1 - __uint_as_float((uint32_t)pm << 16);
-            const uint16_t pl = to_bf16(r2);
+            uint16_t ph, pm, pl;
+            split3_bf16(x, ph, pm, pl);
             const int KS = HID / 16;
-            uint16_t* base = P.w2x + ((size_t)(k >> 5) * KS + 2 * (f >> 5) + s) * 3 * 512 + ((size_t)(k & 31) + 32 * hh) * 8 + jj;
-            base[0] = pl; base[512] = pm; base[1024] = ph;         // [in-feature tile][k-step][piece lo, mid, hi][64 lanes][8]
+            int s, hh, jj;
+            {   // backward: dH1[row, k] = sum_f dZ2[row, f] W[f][k]: B operand, column k, contraction f in the register order
+                // of the packed dZ2 accumulator tile; [in-feature tile][k-step][piece lo, mid, hi][64 lanes][8]
+                acc_kslot(f & 31, s, hh, jj);
+                uint16_t* base = P.w2x + ((size_t)(k >> 5) * KS + 2 * (f >> 5) + s) * 3 * 512 + ((size_t)(k & 31) + 32 * hh) * 8 + jj;
+                base[0] = pl; base[512] = pm; base[1024] = ph;
+            }
+            {   // train forward: H2^T[f, row] = sum_k W[f][k] H1[row, k]: A operand, row f, contraction k in the register order
+                // of the packed H1 accumulator tile
+                acc_kslot(k & 31, s, hh, jj);
+                uint16_t* base = P.w2fx + ((size_t)(f >> 5) * KS + 2 * (k >> 5) + s) * 3 * 512 + ((size_t)(f & 31) + 32 * hh) * 8 + jj;
+                base[0] = pl; base[512] = pm; base[1024] = ph;
+            }
         }
         if (P.w2b) {
             const uint16_t xb = to_bf16(x);
@@ -238,7 +256,7 @@ static PackPtrs packs_of(ppo_policy_s* p) {
     const bool b = (p->dtype == PPO_DTYPE_BF16);
     P.w1b = b ? p->w1b.p : nullptr; P.w2b = b ? p->w2b.p : nullptr; P.w2tb = b ? p->w2tb.p : nullptr;
     P.w3c = b ? p->w3c.p : nullptr; P.w3tb = b ? p->w3tb.p : nullptr;
-    P.w2x = p->w2x.p;
+    P.w2x = p->w2x.p; P.w1x = p->w1x.p; P.w2fx = p->w2fx.p;
     return P;
 }
 

@@ -36,46 +36,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 xbf16x2 __attribute__((ext_vector_type(2)));
-typedef float xf32x2 __attribute__((ext_vector_type(2)));
-typedef short xs16x4 __attribute__((ext_vector_type(4)));
+#include "ppo_x6.h"
 typedef float pk2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-__device__ __forceinline__ uint32_t x_pack(float lo, float hi) {             // v_cvt_pk_bf16_f32 (RNE)
-    const xf32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xbf16x2));
-}
-__device__ __forceinline__ f32x16 x_mfma(const uint4& a, const uint4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(xbf16x8, a), __builtin_bit_cast(xbf16x8, b), c, 0, 0, 0);
-}
-// four fp32 values -> three packed bf16 pieces (two dwords each): a = h + m + l exactly up to 2^-26 |a|
-__device__ __forceinline__ void x_split4(const float (&a)[4], uint2& ph, uint2& pm, uint2& pl) {
-    uint32_t P[2], M[2], L[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const float a0 = a[2 * u], a1 = a[2 * u + 1];
-        P[u] = x_pack(a0, a1);
-        const float r0 = a0 - __uint_as_float(P[u] << 16), r1 = a1 - __uint_as_float(P[u] & 0xFFFF0000u);      // exact
-        M[u] = x_pack(r0, r1);
-        const float s0 = r0 - __uint_as_float(M[u] << 16), s1 = r1 - __uint_as_float(M[u] & 0xFFFF0000u);      // exact
-        L[u] = x_pack(s0, s1);
-    }
-    ph = make_uint2(P[0], P[1]); pm = make_uint2(M[0], M[1]); pl = make_uint2(L[0], L[1]);
-}
-// two fp32 registers that hold exact bf16 values -> one packed dword {lo16 = a, hi16 = b}
-__device__ __forceinline__ uint32_t x_perm(float a, float b) {
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-// two transposed 4x16 block reads -> one 32x32x16 operand fragment
-__device__ __forceinline__ uint4 x_tr_frag(const char* p0, const char* p1) {
-    typedef __attribute__((address_space(3))) xs16x4 lds_s16x4;
-    const xs16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
-    const xs16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
-    const uint2 a = __builtin_bit_cast(uint2, u0), b = __builtin_bit_cast(uint2, u1);
-    return make_uint4(a.x, a.y, b.x, b.y);
-}
 
 struct BwdXArgs {
     unsigned long long* stamps;   // diagnostic build only (-DPPO_X6_STAMP): [nwg][2 waves][12 phases]
@@ -106,8 +69,13 @@ struct XCfg {
 // VALU ops, instead of living in ~30 loop-invariant registers that hipcc hoists out of the tile loop and spills
 #define X6_LANE() unsigned ln = (unsigned)lane; asm volatile("" : "+v"(ln)); const int j = (int)(ln & 31u), h = (int)(ln >> 5); (void)j; (void)h
 
+// W2 piece fragments in flight ahead of the dH1 chain (3 per k-step).  HID = 256 runs at the 256-register budget: with
+// the chain's two accumulators a ring of 6 spills one accumulator tile inside the chain loop, 3 fits
 #ifndef PPO_X6_RING
-#define PPO_X6_RING 6                 // W2 piece fragments in flight ahead of the dH1 chain (3 per k-step)
+#define PPO_X6_RING 6
+#endif
+#ifndef PPO_X6_RING_256
+#define PPO_X6_RING_256 3
 #endif
 
 template <int F, int HID>
@@ -115,7 +83,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
     using C = XCfg<F, HID>;
     constexpr int NT = C::NT, KS = C::KS, NTHR = NT * 64, LD = C::LD, NIX = C::NIX, XROW = C::XROW;
     constexpr int XQW = 32 * F / 8, XPD = (XQW + NTHR - 1) / NTHR;
-    constexpr int RD = PPO_X6_RING;
+    constexpr int RD = HID >= 256 ? PPO_X6_RING_256 : PPO_X6_RING;
     static_assert(NTHR >= 256 && NTHR >= HID, "shape");
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     char* const fragZ2 = smem_c + C::oZ2;
@@ -338,6 +306,14 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
             // one pass over the k-steps; per k-step the three W2 pieces (lo, mid, hi: 1 + 2 + 3 MFMAs against the dZ2 pieces).
             // The stream pointer is a scalar that advances 1 KiB per piece, the fragment pointer advances per ring round:
             // nothing here is a per-step address the compiler could hoist out of the tile loop and spill
+            // The leading terms (h h) and the small ones (h m + m h, 2^-8; h l + m m + l h, 2^-16) in separate accumulators,
+            // added at the end: inside one MFMA the 16 products and the accumulator are aligned to the largest of them before
+            // they are added (tools/microbench/mfma_bf16_accumulate.hip), so small terms fed into the leading running sum
+            // would lose their low bits at every one of the 6 KS steps; summed among themselves they keep them (the 2^-16
+            // terms then lose bits 2^-32 of the result).
+            f32x16 accs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
             const char* wn = wx + (size_t)RD * 1024;
             static_assert(RD % 3 == 0 && KS % (RD / 3) == 0, "ring rounds");
             unsigned zo = (unsigned)lane * 16u;
@@ -351,17 +327,17 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                     const uint4 z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
                     const uint4 z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
                     const uint4 z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
-                    acc = x_mfma(z_h, ring[3 * u + 0], acc);
+                    accs = x_mfma(z_h, ring[3 * u + 0], accs);
                     __builtin_amdgcn_sched_barrier(0);
                     ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
                     __builtin_amdgcn_sched_barrier(0);
-                    acc = x_mfma(z_m, ring[3 * u + 1], acc);
-                    acc = x_mfma(z_h, ring[3 * u + 1], acc);
+                    accs = x_mfma(z_m, ring[3 * u + 1], accs);
+                    accs = x_mfma(z_h, ring[3 * u + 1], accs);
                     __builtin_amdgcn_sched_barrier(0);
                     ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc = x_mfma(z_l, ring[3 * u + 2], acc);
-                    acc = x_mfma(z_m, ring[3 * u + 2], acc);
+                    accs = x_mfma(z_l, ring[3 * u + 2], accs);
+                    accs = x_mfma(z_m, ring[3 * u + 2], accs);
                     acc = x_mfma(z_h, ring[3 * u + 2], acc);
                     __builtin_amdgcn_sched_barrier(0);
                     ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
@@ -370,6 +346,8 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 }
                 zp += (RD / 3) * 3 * 1024;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + accs[r];
             XSTAMP(5);
             // acc: dH1, lane = feature 32w + j, register r <-> tile row (r&3) + 8(r>>2) + 4h.  dZ1 = dH1 . lrelu'(H1): the sign
             // of H1 from the first piece of its image, read transposed (block rows 8g + 4h .. +3 = registers 4g .. 4g+3)

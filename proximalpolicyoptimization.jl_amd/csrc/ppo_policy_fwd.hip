@@ -687,6 +687,10 @@ int32_t launch_policy_train_fwd(ppo_policy_s* p, ppo_rollouts_s* ro, const int32
         a.states = nullptr; a.cstate = ro->cstate.p; a.xs_out = p->xs.p;
         a.env_tmpl = ro->tmpl.p; a.envV = ro->V; a.envQ = ro->V / 4; a.env_slots = 1;
     }
+    {   // Dense products as split-fp32 MFMAs on the bf16 pipe (ppo_policy_fwd_x6.hip: fp32 Policy(72, h, 2, 4), expanded states)
+        const int32_t rx = launch_policy_train_fwd_x6(p, a, B, ro->H / 32, ro->compact);
+        if (rx != PPO_ERR_UNSUPPORTED) return rx;
+    }
     if (B <= g_fwd_split_max_states) {        // small minibatch: 2 or 4 waves per state (ppo_policy_fwd_split.hip)
         const int32_t rs = launch_policy_train_fwd_split(p, a, B, ro->H / 32, ro->compact);
         if (rs != PPO_ERR_UNSUPPORTED) return rs;

@@ -1,0 +1,266 @@
+// ppo_policy_fwd_x6.hip -- the TRAIN forward (policy + ppo_loss_with_entropy terms + dL/dlogits: src/train.jl:35-46,65-79
+// forward half; test/policy.jl:21-31) with its two Dense products on the bf16 matrix pipe as split-fp32 ("bf16x6")
+// products, like the backward in ppo_policy_bwd_x6.hip.  Rollouts and the probability entry points keep the fp32-MFMA
+// kernel (their sampled actions are pinned bit for bit); the train forward's outputs -- saved activations, dL/dlogits, the
+// two loss sums -- feed tolerance-checked quantities only (gradient within 2e-5 max|g| of the float64 restatement).
+//
+// Shape of the kernel: a workgroup of HID/32 waves owns a 32-row tile (one state), wave w owns feature tile w of both hidden
+// layers (the k_policy_train_tile arrangement):
+//   layer 1   H1^T[f, row] = lrelu(W1 X^T + b1): A = W1 pieces streamed from L2 (3 x 5 k-steps), B = the state rows, exact
+//             in bf16 (converted in registers by every wave: 2.3 KB from L1/L2) -> 15 MFMAs; the tile is stored for the
+//             backward (accumulator-fragment order, as k_policy_fwd does) and, split in three, written to LDS as the
+//             B-operand fragments of layer 2 (the packed accumulator registers ARE that operand)
+//   layer 2   H2^T = lrelu(W2 H1^T + b2): A = W2 pieces from L2 (lo, mid, hi per k-step: 1 + 2 + 3 MFMAs), B = the H1
+//             fragments of all feature tiles from LDS -> 96 MFMAs; stored; layer-3 partial dots on the VALU (fp32, as in
+//             every forward) -> LDS; wave 0 adds the partials in wave order and runs the shared loss tail (policy_tail)
+// 128 registers per wave and 62 KB of LDS per workgroup: TWO workgroups share a CU at HID = 256 (four at 128) and run out
+// of phase, so one workgroup's conversions / splits / tail sit beside the other's MFMAs.
+// The weights stream from L2 once per TILE (63 KB per wave, 0.5 MB per tile and CU: 2 GB per 4096-state launch, which the
+// eight L2s deliver).  Measured against the one-wave-per-state fp32-MFMA forward (gpurun_out/x6h, same box): 4096 states
+// 0.211 -> 0.142 ms, 2048 0.110 -> 0.075, 1024 0.059 -> 0.039, 512 0.031 -> 0.023.  ppo_set_bwd_split_bf16(0) or
+// PPO_FWD_SPLIT_MAX_TILES=0 select the fp32-MFMA forward.
+#include "ppo_policy_tail.h"
+#include "ppo_x6.h"
+#include <cstdlib>
+
+#define X6F_LANE() unsigned ln = (unsigned)lane; asm volatile("" : "+v"(ln)); const int j = (int)(ln & 31u), h = (int)(ln >> 5); (void)j; (void)h
+
+template <int HID>
+struct FXCfg {
+    static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;     // layer-1 k-steps: 72 inputs zero padded to 80
+    static constexpr size_t oFr = 0, szFr = (size_t)NT * 6 * 1024;         // H1 fragments [feature tile][k-step 2][piece 3][64 lanes][16 B]
+    static constexpr size_t oP = oFr + szFr, oW3 = oP + (size_t)NT * 1024, oB1 = oW3 + (size_t)2 * NT * 256,
+                            oB2 = oB1 + (size_t)NT * 128, total = oB2 + (size_t)NT * 128;
+    static constexpr int WG_PER_CU = HID == 256 ? 2 : 4;
+    static_assert(total * WG_PER_CU <= 160 * 1024, "LDS budget");
+};
+
+template <int HID>
+__global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, const uint4* __restrict__ w1x, const uint4* __restrict__ w2fx) {
+    using C = FXCfg<HID>;
+    constexpr int F = C::F, NT = C::NT, KS = C::KS, K1 = C::K1;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* const frag = smem_c + C::oFr;
+    float4* const sP = reinterpret_cast<float4*>(smem_c + C::oP);          // [NT][64] layer-3 partial dots
+    float4* const sW3p = reinterpret_cast<float4*>(smem_c + C::oW3);       // [2][NT][16] the forward's layer-3 pack
+    float4* const sB1 = reinterpret_cast<float4*>(smem_c + C::oB1);        // [NT][2][4]
+    float4* const sB2 = reinterpret_cast<float4*>(smem_c + C::oB2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * NT * 16; i += NT * 64) sW3p[i] = a.w3p[i];
+    for (int i = tid; i < NT * 8; i += NT * 64) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    __syncthreads();
+    const char* const w1s = reinterpret_cast<const char*>(w1x + (size_t)w * K1 * 3 * 64);     // [k-step][piece lo, mid, hi][64][8]
+    const char* const w2s = reinterpret_cast<const char*>(w2fx + (size_t)w * KS * 3 * 64);
+    char* const fown = frag + (size_t)w * 6 * 1024;
+
+    // the state rows of a tile as this lane's B-operand source: 8 int8 per k-step, inputs 16s + 8h .. +7 of row j
+    uint2 xr[K1];
+    auto load_x = [&](int32_t sid, unsigned ln) {
+        const char* row = reinterpret_cast<const char*>(a.states) + (size_t)sid * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+            // k-step 4 covers inputs 64 .. 79: the upper lane half (72 .. 79) is padding (and would read past the row)
+            const bool pad = (s == K1 - 1) && (ln >> 5);
+            const uint2 v = *reinterpret_cast<const uint2*>(row + (pad ? 0 : 16 * s));
+            xr[s] = pad ? make_uint2(0u, 0u) : v;
+        }
+    };
+    int32_t sid = 0;
+    if ((int64_t)blockIdx.x < a.B) { sid = __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x]); load_x(sid, (unsigned)lane); }
+
+    for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
+        const uint32_t act = a.active[sid];
+        const int32_t sid_cur = sid;
+        // ================= layer 1: H1 tile w
+        {
+            X6F_LANE();
+            unsigned lo16 = ln * 16u;
+            constexpr int R1 = 8;                                   // W1 piece fragments in flight
+            uint4 ring[R1];
+#pragma unroll
+            for (int g = 0; g < R1; ++g) ring[g] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)g * 1024u));
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = sB1[(w * 2 + h) * 4 + q];
+                acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
+            // int8 -> bf16 (exact): the float of the byte, upper 16 bits
+            uint4 xb[K1];
+#pragma unroll
+            for (int s = 0; s < K1; ++s) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)(int)(int8_t)((e < 4 ? xr[s].x : xr[s].y) >> (8 * (e & 3)));
+                xb[s] = make_uint4(x_perm(v[0], v[1]), x_perm(v[2], v[3]), x_perm(v[4], v[5]), x_perm(v[6], v[7]));
+            }
+            f32x16 accs;                                            // the mid and lo pieces of W1 (2^-8, 2^-16 of the leading terms)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 3 * K1; ++st) {
+                if (st % 3 == 2) acc = x_mfma(ring[st % R1], xb[st / 3], acc);
+                else accs = x_mfma(ring[st % R1], xb[st / 3], accs);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + R1 < 3 * K1) ring[st % R1] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)(st + R1) * 1024u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + accs[r];
+            asm volatile("" : "+v"(acc));
+            lrelu16(acc);
+            float4* dst = a.act1 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                typedef float f32x4l __attribute__((ext_vector_type(4)));
+                const f32x4l t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+            }
+            // registers 8s .. 8s+7, split and packed = the B-operand fragment of k-step (w, s) of layer 2
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint2 zh[2], zm[2], zl[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * s + qq;
+                    const float hv[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    x_split4(hv, zh[qq], zm[qq], zl[qq]);
+                }
+                *reinterpret_cast<uint4*>(fown + (s * 3 + 0) * 1024 + ln * 16) = make_uint4(zh[0].x, zh[0].y, zh[1].x, zh[1].y);
+                *reinterpret_cast<uint4*>(fown + (s * 3 + 1) * 1024 + ln * 16) = make_uint4(zm[0].x, zm[0].y, zm[1].x, zm[1].y);
+                *reinterpret_cast<uint4*>(fown + (s * 3 + 2) * 1024 + ln * 16) = make_uint4(zl[0].x, zl[0].y, zl[1].x, zl[1].y);
+            }
+        }
+        // the W2 piece ring of layer 2 is in flight across the barrier; so are the next tile's state rows
+        constexpr int RD = 6;
+        static_assert(KS % (RD / 3) == 0, "ring rounds");
+        uint4 ring[RD];
+        {
+            unsigned lo = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int g = 0; g < RD; ++g) ring[g] = *reinterpret_cast<const uint4*>(w2s + (lo + (unsigned)g * 1024u));
+        }
+        const int64_t ntile = (tile + gridDim.x < a.B) ? tile + gridDim.x : tile;
+        {
+            unsigned ln2 = (unsigned)lane;
+            asm volatile("" : "+v"(ln2));
+            sid = __builtin_amdgcn_readfirstlane(a.idx[ntile]);
+            load_x(sid, ln2);
+        }
+        __syncthreads();                                                // (1) every layer-1 tile is in LDS
+        // ================= layer 2: H2 tile w from all layer-1 tiles; layer-3 partial dots
+        {
+            X6F_LANE();
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = sB2[(w * 2 + h) * 4 + q];
+                acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+            }
+            // one accumulator per term level (h h | h m + m h | h l + m m + l h): the 2^-8 and 2^-16 terms are summed among
+            // themselves and meet the leading sum in two fp32 additions at the end.  Inside one MFMA the 16 products and the
+            // accumulator are aligned to the largest of them before they are added (tools/microbench/mfma_bf16_accumulate.hip):
+            // small terms fed into the leading accumulator would lose their low bits 96 times per output
+            f32x16 accm, accl;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[r] = 0.0f; accl[r] = 0.0f; }
+            const unsigned lo16 = ln * 16u;
+            const char* zp = frag + lo16;
+            const char* wn = w2s + (size_t)RD * 1024;
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS; k0 += RD / 3) {
+#pragma unroll
+                for (int u = 0; u < RD / 3; ++u) {
+                    const uint4 z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
+                    const uint4 z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
+                    const uint4 z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
+                    accl = x_mfma(ring[3 * u + 0], z_h, accl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl = x_mfma(ring[3 * u + 1], z_m, accl);
+                    accm = x_mfma(ring[3 * u + 1], z_h, accm);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accl = x_mfma(ring[3 * u + 2], z_l, accl);
+                    accm = x_mfma(ring[3 * u + 2], z_m, accm);
+                    acc = x_mfma(ring[3 * u + 2], z_h, acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    wn += 3 * 1024;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                zp += (RD / 3) * 3 * 1024;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + (accm[r] + accl[r]);
+            asm volatile("" : "+v"(acc));
+            lrelu16(acc);
+            float4* dst = a.act2 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                typedef float f32x4l __attribute__((ext_vector_type(4)));
+                const f32x4l t = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+            }
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            const float4* w3 = sW3p + (h * NT + w) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float4 wv = w3[r];
+                p0 = fmaf(wv.x, acc[r], p0); p1 = fmaf(wv.y, acc[r], p1);
+                p2 = fmaf(wv.z, acc[r], p2); p3 = fmaf(wv.w, acc[r], p3);
+            }
+            sP[w * 64 + ln] = make_float4(p0, p1, p2, p3);
+        }
+        __syncthreads();                                                // (2) every wave's partial logits are in LDS; the H1 fragments are free
+        if (w == 0) {
+            // partial logits in wave (= feature tile) order, the two lane halves, b3; then the epilogue every forward shares
+            X6F_LANE();
+            float4 s = sP[ln];
+#pragma unroll
+            for (int u = 1; u < NT; ++u) { const float4 q4 = sP[u * 64 + ln]; s.x += q4.x; s.y += q4.y; s.z += q4.z; s.w += q4.w; }
+            float l[1][4];
+            l[0][0] = (s.x + __shfl_xor(s.x, 32)) + a.b3[0];
+            l[0][1] = (s.y + __shfl_xor(s.y, 32)) + a.b3[1];
+            l[0][2] = (s.z + __shfl_xor(s.z, 32)) + a.b3[2];
+            l[0][3] = (s.w + __shfl_xor(s.w, 32)) + a.b3[3];
+            policy_tail<2, 1, false>(a, tile, sid_cur, act, l, (int)ln, j, h);
+        }
+    }
+}
+
+// minibatches of up to this many 32-row tiles take the split-fp32 train forward (when ppo_set_bwd_split_bf16 is on);
+// PPO_FWD_SPLIT_MAX_TILES overrides (0 = never)
+#ifndef PPO_FWD_X6_DEFAULT_MAX_TILES
+#define PPO_FWD_X6_DEFAULT_MAX_TILES (1 << 30)
+#endif
+static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_DEFAULT_MAX_TILES; }();
+
+int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
+    if (!ppo_bwd_split_enabled() || B > g_fwd_x6_max_tiles) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || tps != 1 || compact || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
+#define LAUNCH(HH)                                                                                           \
+    do {                                                                                                     \
+        const int64_t cap = 256 * FXCfg<HH>::WG_PER_CU;                                                      \
+        const int nwg = (int)(B < cap ? B : cap);                                                            \
+        const size_t lds = FXCfg<HH>::total;                                                                 \
+        static thread_local bool attr_set = false;                                                           \
+        if (!attr_set) {                                                                                     \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_x6<HH>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((k_policy_fwd_train_x6<HH>), dim3(nwg), dim3(HH * 2), lds, ppo_stream(), a,       \
+                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p);                                 \
+    } while (0)
+    if (p->HID == 256) LAUNCH(256);
+    else if (p->HID == 128) LAUNCH(128);
+    else return PPO_ERR_UNSUPPORTED;
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return PPO_OK;
+}

@@ -390,7 +390,7 @@ def bwd_form(request, P):
         P.set_train_tile_max_tiles(0)
         P.set_bwd_small_max_tiles(max(request.param, 0))
         P.set_fwd_split_max_states(min(max(request.param, 0), 512))
-        if request.param == -2:
+        if request.param in (-2, 4096):      # the fp32-MFMA forms of the large- and the small-minibatch kernels
             P.set_bwd_split_bf16(False)
     yield request.param
     P.set_bwd_split_bf16(None)
