@@ -462,18 +462,30 @@ def main():
             iteration(args.warmup + args.steps + 1)
             PPO.synchronize()
             ms, n = PPO.profile_get("k_policy_bwd")
+            fms, fn = PPO.profile_get("k_policy_fwd_train")
             PPO.profile_enable(False)
             PPO.set_bwd_split_bf16(None)
             if n:
                 tf = flops_per_state("bwd") * MINIBATCH / (ms / n * 1e-3) / 1e12
                 fp32_form = {"kernel": "k_policy_bwd<F,HID> (v_mfma_f32_32x32x2_f32: ppo_set_bwd_split_bf16(0))", "avg_ms": round(ms / n, 4),
                              "launches": n, "tflops": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+                if fn:
+                    ftf = flops_per_state("fwd") * MINIBATCH / (fms / fn * 1e-3) / 1e12
+                    fp32_form["train_forward"] = {"kernel": "k_policy_fwd<F,HID,MODE 2> (fp32 MFMA, one wave per state)", "avg_ms": round(fms / fn, 4),
+                                                  "tflops": round(ftf, 2), "frac": round(ftf / PEAK_FP32_MFMA_TFLOPS, 4)}
         if split_on:
-            kk = kernels["k_policy_bwd"]
-            ratio = split_backward_mfma_flops_per_state() / flops_per_state("bwd")
-            kk["executed_bf16_mfma_tflops"] = round(kk["tflops"] * ratio, 1)
-            kk["frac"] = round(kk["tflops"] * ratio / PEAK_BF16_MFMA_TFLOPS, 4)           # of the pipe that bounds it
-            kk["algorithmic_over_fp32_mfma_peak"] = round(kk["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+            rows = 4 * QUADS
+            # bf16 MFMA flops the split kernels EXECUTE per algorithmic flop: backward see split_backward_mfma_flops_per_state;
+            # train forward: layer 1 three piece products (X exact in bf16, 72 inputs padded to 80), layer 2 six, layer 3 on the VALU
+            for name, ratio in (("k_policy_bwd", split_backward_mfma_flops_per_state() / flops_per_state("bwd")),
+                                ("k_policy_fwd_train", 2 * rows * (3 * HID * 80 + 6 * HID * HID) / flops_per_state("fwd"))):
+                kk = kernels.get(name)
+                if not kk or (name == "k_policy_fwd_train" and (QUADS != 8 or os.environ.get("PPO_FWD_SPLIT_MAX_TILES") == "0")):
+                    continue
+                kk["executed_bf16_mfma_tflops"] = round(kk["tflops"] * ratio, 1)
+                kk["frac"] = round(kk["tflops"] * ratio / PEAK_BF16_MFMA_TFLOPS, 4)       # of the pipe that bounds it
+                kk["algorithmic_over_fp32_mfma_peak"] = round(kk["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                kk["form"] = "split-fp32 (bf16x6) on the bf16 MFMA pipe"
         k = kernels.get("k_policy_bwd+k_policy_dw1") or kernels.get("k_policy_bwd") or kernels.get("k_policy_bwd_data+k_policy_wgrad")
         if k:
             # HBM bytes per launch of the dominant kernel come from the committed PMC passes (rocprofv3 cannot run
@@ -562,7 +574,7 @@ def main():
                        "rollouts_streamed_to_disk": bool(args.stream),
                        # fp32 data, fp32 accumulation everywhere; the fused backward's three big products run as split-fp32
                        # (three exact bf16 pieces per operand, six piece products) on the bf16 matrix pipe unless switched off
-                       "backward_products": ("split-fp32 (bf16x6) on the bf16 MFMA pipe, fp32 accumulate" if split_backward_on(args.dtype)
+                       "training_pass_products": ("split-fp32 (bf16x6) on the bf16 MFMA pipe, fp32 accumulate (train forward + backward; rollouts: fp32 MFMA)" if split_backward_on(args.dtype)
                                              else ("fp32 MFMA" if args.dtype == "f32" else "bf16 MFMA"))},
             "allreduce": (dp.hook_kind if use_dist else None), "rccl_ranks": (comm[1] if comm else None),
             "strong": strong,

@@ -156,8 +156,10 @@ __global__ void k_env_snapshot(EnvView e, uint32_t* __restrict__ out) {
 
 // state(env) from stored snapshots (getters / exporter of the compact form): same arithmetic as k_env_observe with the
 // score / degree bytes taken from record n of `cstate` instead of the live env arrays
+// idx (optional): record n of the output is transition idx[n] (a minibatch in minibatch order) instead of record n
 __global__ void k_expand_states(const int8_t* __restrict__ cstate, const uint32_t* __restrict__ active,
-                                const int8_t* __restrict__ tmpl, int64_t count, int Q, int8_t* __restrict__ obs) {
+                                const int8_t* __restrict__ tmpl, int64_t count, int Q, int8_t* __restrict__ obs,
+                                const int32_t* __restrict__ idx) {
     const int H = 4 * Q, F = 2 * PPO_TPL, V = 4 * Q;
     const int dw_per_env = H * F / 4;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,8 +167,9 @@ __global__ void k_expand_states(const int8_t* __restrict__ cstate, const uint32_
     if (n >= count) return;
     const int rem = (int)(gid - n * dw_per_env);
     const int h = rem / (F / 4), f0 = (rem % (F / 4)) * 4;
-    const uint32_t act = active[n];
-    const int8_t* src = cstate + n * 2 * V + ((f0 < PPO_TPL) ? 0 : V);
+    const int64_t rec = idx ? (int64_t)idx[n] : n;
+    const uint32_t act = active[rec];
+    const int8_t* src = cstate + rec * 2 * V + ((f0 < PPO_TPL) ? 0 : V);
     const int t0 = (f0 < PPO_TPL) ? f0 : f0 - PPO_TPL;
     const bool own = (act >> (h >> 2)) & 1u;
     const uint32_t ids = *reinterpret_cast<const uint32_t*>(tmpl + h * PPO_TPL + t0);
@@ -190,11 +193,11 @@ int32_t launch_env_snapshot(ppo_env_s* e, int8_t* cstate_out) {
 }
 
 int32_t launch_expand_states(const int8_t* cstate, const uint32_t* active, const int8_t* tmpl, int64_t count, int32_t Q,
-                             int8_t* obs_out) {
+                             int8_t* obs_out, const int32_t* idx) {
     if (count <= 0) return PPO_OK;
     const int64_t total = count * (int64_t)(4 * Q * 2 * PPO_TPL / 4);
     hipLaunchKernelGGL(k_expand_states, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppo_stream(), cstate, active,
-                       tmpl, count, (int)Q, obs_out);
+                       tmpl, count, (int)Q, obs_out, idx);
     HIP_TRY(hipGetLastError());
     return PPO_OK;
 }

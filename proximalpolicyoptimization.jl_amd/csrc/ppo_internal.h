@@ -215,8 +215,9 @@ int32_t launch_env_observe(ppo_env_s* e, int8_t* obs_out, uint32_t* active_out);
 // compact rollout storage: env snapshot of every env (score[V] then degree[V]) -> cstate_out [N][2V]
 int32_t launch_env_snapshot(ppo_env_s* e, int8_t* cstate_out);
 // snapshots -> observations (the same arithmetic as state(env)): count records of 2V bytes -> [count][H][F]
+// idx (optional): output record n = transition idx[n] (a gathered minibatch) instead of record n
 int32_t launch_expand_states(const int8_t* cstate, const uint32_t* active, const int8_t* tmpl, int64_t count, int32_t Q,
-                             int8_t* obs_out);
+                             int8_t* obs_out, const int32_t* idx = nullptr);
 
 int32_t launch_pack_params(ppo_policy_s* p);
 int32_t launch_policy_probs(ppo_policy_s* p, const int8_t* states_dev, const uint32_t* active_dev, int64_t B,

@@ -36,7 +36,7 @@ struct FXCfg {
 };
 
 template <int HID>
-__global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, const uint4* __restrict__ w1x, const uint4* __restrict__ w2fx) {
+__global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, const uint4* __restrict__ w1x, const uint4* __restrict__ w2fx, int x_by_tile) {
     using C = FXCfg<HID>;
     constexpr int F = C::F, NT = C::NT, KS = C::KS, K1 = C::K1;
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -56,8 +56,9 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
 
     // the state rows of a tile as this lane's B-operand source: 8 int8 per k-step, inputs 16s + 8h .. +7 of row j
     uint2 xr[K1];
-    auto load_x = [&](int32_t sid, unsigned ln) {
-        const char* row = reinterpret_cast<const char*>(a.states) + (size_t)sid * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
+    // (x_by_tile: `states` holds the minibatch's rows in minibatch order -- compact rollouts, expanded by k_expand_states)
+    auto load_x = [&](int64_t rec, unsigned ln) {
+        const char* row = reinterpret_cast<const char*>(a.states) + (size_t)rec * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
 #pragma unroll
         for (int s = 0; s < K1; ++s) {
             // k-step 4 covers inputs 64 .. 79: the upper lane half (72 .. 79) is padding (and would read past the row)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
         }
     };
     int32_t sid = 0;
-    if ((int64_t)blockIdx.x < a.B) { sid = __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x]); load_x(sid, (unsigned)lane); }
+    if ((int64_t)blockIdx.x < a.B) { sid = __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x]); load_x(x_by_tile ? (int64_t)blockIdx.x : (int64_t)sid, (unsigned)lane); }
 
     for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
         const uint32_t act = a.active[sid];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
             unsigned ln2 = (unsigned)lane;
             asm volatile("" : "+v"(ln2));
             sid = __builtin_amdgcn_readfirstlane(a.idx[ntile]);
-            load_x(sid, ln2);
+            load_x(x_by_tile ? ntile : (int64_t)sid, ln2);
         }
         __syncthreads();                                                // (1) every layer-1 tile is in LDS
         // ================= layer 2: H2 tile w from all layer-1 tiles; layer-3 partial dots
@@ -242,7 +243,14 @@ static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SP
 
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
     if (!ppo_bwd_split_enabled() || B > g_fwd_x6_max_tiles) return PPO_ERR_UNSUPPORTED;
-    if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || tps != 1 || compact || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || tps != 1 || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
+    if (compact) {
+        // env snapshots: the minibatch's observation rows are re-derived first (the arithmetic of state(env), ppo_env.hip) into
+        // the scratch the backward reads in this storage form anyway; both kernels then see the rows the expanded form holds,
+        // so the storage form does not change a bit of the result
+        PPO_TRY(launch_expand_states(a.cstate, a.active, a.env_tmpl, B, a.envQ, a.xs_out, a.idx));
+        a.states = a.xs_out;
+    }
 #define LAUNCH(HH)                                                                                           \
     do {                                                                                                     \
         const int64_t cap = 256 * FXCfg<HH>::WG_PER_CU;                                                      \
@@ -255,7 +263,7 @@ int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int t
             attr_set = true;                                                                                 \
         }                                                                                                    \
         hipLaunchKernelGGL((k_policy_fwd_train_x6<HH>), dim3(nwg), dim3(HH * 2), lds, ppo_stream(), a,       \
-                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p);                                 \
+                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);                                 \
     } while (0)
     if (p->HID == 256) LAUNCH(256);
     else if (p->HID == 128) LAUNCH(128);
