@@ -23,6 +23,12 @@
 #include "ppo_x6.h"
 #include <cstdlib>
 
+#ifndef PPO_FX6_RING
+#define PPO_FX6_RING 6                // W2 piece fragments in flight ahead of layer 2 (3 per k-step)
+#endif
+#ifndef PPO_FX6_ACC3
+#define PPO_FX6_ACC3 1                // 1: one accumulator per term level (3); 0: leading + small (2)
+#endif
 #define X6F_LANE() unsigned ln = (unsigned)lane; asm volatile("" : "+v"(ln)); const int j = (int)(ln & 31u), h = (int)(ln >> 5); (void)j; (void)h
 
 template <int HID>
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
             }
         }
         // the W2 piece ring of layer 2 is in flight across the barrier; so are the next tile's state rows
-        constexpr int RD = 6;
-        static_assert(KS % (RD / 3) == 0, "ring rounds");
+        constexpr int RD = PPO_FX6_RING;
+        static_assert(RD % 3 == 0 && KS % (RD / 3) == 0, "ring rounds");
         uint4 ring[RD];
         {
             unsigned lo = (unsigned)lane * 16u;
@@ -164,9 +170,10 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
             // themselves and meet the leading sum in two fp32 additions at the end.  Inside one MFMA the 16 products and the
             // accumulator are aligned to the largest of them before they are added (tools/microbench/mfma_bf16_accumulate.hip):
             // small terms fed into the leading accumulator would lose their low bits 96 times per output
-            f32x16 accm, accl;
+            f32x16 accm, accl_;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[r] = 0.0f; accl[r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) { accm[r] = 0.0f; accl_[r] = 0.0f; }
+            f32x16& accl = PPO_FX6_ACC3 ? accl_ : accm;
             const unsigned lo16 = ln * 16u;
             const char* zp = frag + lo16;
             const char* wn = w2s + (size_t)RD * 1024;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
                 zp += (RD / 3) * 3 * 1024;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + (accm[r] + accl[r]);
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] + (PPO_FX6_ACC3 ? accm[r] + accl_[r] : accm[r]);
             asm volatile("" : "+v"(acc));
             lrelu16(acc);
             float4* dst = a.act2 + ((size_t)tile * NT + w) * 4 * 64;

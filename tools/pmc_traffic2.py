@@ -32,7 +32,7 @@ res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separa
 for arg in sys.argv[2:]:
     key, d = arg.rsplit("=", 1)
     ks = passes(d)
-    bwd = [v for k, v in ks.items() if k.startswith("k_policy_bwd<") or k.startswith("k_policy_bwd_bf16")]
+    bwd = [v for k, v in ks.items() if k.startswith("k_policy_bwd<") or k.startswith("k_policy_bwd_x6") or k.startswith("k_policy_bwd_bf16")]
     if not bwd:      # three-product backward (deep policies): the pair
         pair = [v for k, v in ks.items() if k.startswith("k_policy_bwd_data") or k.startswith("k_policy_wgrad")]
         bwd = [{"hbm_bytes": sum(v["hbm_bytes"] for v in pair)}] if pair else []
