@@ -598,6 +598,9 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         }
     }
     if (tid < 4) sb3[tid] = db3;
+    // the LDS-DMA issued for the (re-loaded) last tile must have landed before the workgroup's LDS is released to the next
+    // workgroup on this CU (see ppo_policy_bwd_x6.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 #ifdef PPO_BWD_STAMP

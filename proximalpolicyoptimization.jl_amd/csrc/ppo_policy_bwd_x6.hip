@@ -109,6 +109,10 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
         for (int r = 0; r < 16; ++r) accW1[it][r] = 0.0f;
     float db2 = 0.f, db3 = 0.f, dw3[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef PPO_X6_ZERO_LDS
+    for (int i = tid; i < (int)(C::total / 4); i += NTHR) reinterpret_cast<uint32_t*>(smem_c)[i] = 0u;
+    __syncthreads();
+#endif
     if (tid < HID) {                                            // w3p is [h][tile][r][4]: un-permute to [f][4]
         const int kk = tid & 31, hh = (kk >> 2) & 1, r = (kk & 3) + 4 * (kk >> 3);
         *reinterpret_cast<float4*>(&sW3[tid * 4]) = a.w3p[(size_t)(hh * NT + (tid >> 5)) * 16 + r];
@@ -520,6 +524,11 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
         }
     }
     if (tid < 4) sb3[tid] = db3;
+    // The last tile's phase C has issued one more set of LDS-DMA loads (a harmless re-load of the same tile).  They must have
+    // LANDED before this wave ends: a DMA that arrives after the workgroup's LDS has been handed to the next workgroup on the
+    // CU writes into THAT workgroup's LDS (seen as run-to-run differences in a handful of gradient elements at HID = 128, where
+    // the workgroup's tail is short: tools/x6_repro_check2.py).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 #ifdef PPO_X6_STAMP

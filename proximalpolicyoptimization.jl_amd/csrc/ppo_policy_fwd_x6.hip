@@ -53,6 +53,10 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
     float4* const sB2 = reinterpret_cast<float4*>(smem_c + C::oB2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PPO_X6_ZERO_LDS
+    for (int i = tid; i < (int)(C::total / 4); i += NT * 64) reinterpret_cast<uint32_t*>(smem_c)[i] = 0u;
+    __syncthreads();
+#endif
     for (int i = tid; i < 2 * NT * 16; i += NT * 64) sW3p[i] = a.w3p[i];
     for (int i = tid; i < NT * 8; i += NT * 64) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
     __syncthreads();
@@ -241,11 +245,251 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
     }
 }
 
+// ---------------------------------------------------------------- T state tiles per workgroup pass (large minibatches)
+// The one-tile form streams 63 KB of weight pieces per wave and TILE: 2 GB per 4096-state launch = 15 TB/s at its 0.134 ms, i.e.
+// the eight L2s' limit (MI355X_MICROARCH.md: 16.8-18.8 TB/s for lines every workgroup shares).  Here a workgroup takes T tiles
+// through both layers against ONE pass over its weight stream: every W1 / W2 piece fragment feeds T MFMAs.  T x 48 KB of H1
+// fragments: one workgroup per CU, two waves per SIMD; the T independent accumulator chains per wave stand in for the second
+// workgroup's latency hiding.
+template <int HID, int T>
+struct FXTCfg {
+    static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;
+    static constexpr size_t oFr = 0, szFr = (size_t)T * NT * 6 * 1024;
+    static constexpr size_t oP = oFr + szFr, oW3 = oP + (size_t)T * NT * 1024, oB1 = oW3 + (size_t)2 * NT * 256,
+                            oB2 = oB1 + (size_t)NT * 128, total = oB2 + (size_t)NT * 128;
+    static_assert(total <= 160 * 1024, "LDS budget");
+};
+
+template <int HID, int T>
+__global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, const uint4* __restrict__ w1x, const uint4* __restrict__ w2fx, int x_by_tile) {
+    using C = FXTCfg<HID, T>;
+    constexpr int F = C::F, NT = C::NT, KS = C::KS, K1 = C::K1;
+    static_assert(T <= NT, "one tail wave per tile");
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* const frag = smem_c + C::oFr;                                    // [T][feature tile][k-step 2][piece 3][64 lanes][16 B]
+    float4* const sP = reinterpret_cast<float4*>(smem_c + C::oP);          // [T][NT][64] layer-3 partial dots
+    float4* const sW3p = reinterpret_cast<float4*>(smem_c + C::oW3);
+    float4* const sB1 = reinterpret_cast<float4*>(smem_c + C::oB1);
+    float4* const sB2 = reinterpret_cast<float4*>(smem_c + C::oB2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * NT * 16; i += NT * 64) sW3p[i] = a.w3p[i];
+    for (int i = tid; i < NT * 8; i += NT * 64) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    __syncthreads();
+    const char* const w1s = reinterpret_cast<const char*>(w1x + (size_t)w * K1 * 3 * 64);
+    const char* const w2s = reinterpret_cast<const char*>(w2fx + (size_t)w * KS * 3 * 64);
+
+    uint2 xr[T][K1];
+    auto load_x = [&](int i, int64_t rec, unsigned ln) {
+        const char* row = reinterpret_cast<const char*>(a.states) + (size_t)rec * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+            const bool pad = (s == K1 - 1) && (ln >> 5);
+            const uint2 v = *reinterpret_cast<const uint2*>(row + (pad ? 0 : 16 * s));
+            xr[i][s] = pad ? make_uint2(0u, 0u) : v;
+        }
+    };
+    // tile i of group g is g*T + i; a group that runs past the minibatch re-does the last tile and discards it
+    auto tile_of = [&](int64_t g, int i) { const int64_t t = g * T + i; return t < a.B ? t : a.B - 1; };
+    if ((int64_t)blockIdx.x * T < a.B) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int64_t t = tile_of(blockIdx.x, i);
+            load_x(i, x_by_tile ? t : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[t]), (unsigned)lane);
+        }
+    }
+    for (int64_t g = blockIdx.x; g * T < a.B; g += gridDim.x) {
+        // ================= layer 1: H1 tile w of the T states
+        {
+            X6F_LANE();
+            unsigned lo16 = ln * 16u;
+            constexpr int R1 = 8;
+            uint4 ring[R1];
+#pragma unroll
+            for (int q = 0; q < R1; ++q) ring[q] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)q * 1024u));
+            f32x16 acc[T], accs[T];
+            uint4 xb[T][K1];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = sB1[(w * 2 + h) * 4 + q];
+                    acc[i][4 * q + 0] = b.x; acc[i][4 * q + 1] = b.y; acc[i][4 * q + 2] = b.z; acc[i][4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[i][r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < K1; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)(int)(int8_t)((e < 4 ? xr[i][s].x : xr[i][s].y) >> (8 * (e & 3)));
+                    xb[i][s] = make_uint4(x_perm(v[0], v[1]), x_perm(v[2], v[3]), x_perm(v[4], v[5]), x_perm(v[6], v[7]));
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 3 * K1; ++st) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (st % 3 == 2) acc[i] = x_mfma(ring[st % R1], xb[i][st / 3], acc[i]);
+                    else accs[i] = x_mfma(ring[st % R1], xb[i][st / 3], accs[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + R1 < 3 * K1) ring[st % R1] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)(st + R1) * 1024u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] + accs[i][r];
+                asm volatile("" : "+v"(acc[i]));
+                lrelu16(acc[i]);
+                const int64_t tile = g * T + i;
+                if (tile < a.B) {
+                    float4* dst = a.act1 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        typedef float f32x4l __attribute__((ext_vector_type(4)));
+                        const f32x4l t = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+                    }
+                }
+                char* const fown = frag + ((size_t)i * NT + w) * 6 * 1024;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    uint2 zh[2], zm[2], zl[2];
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int q = 2 * s + qq;
+                        const float hv[4] = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        x_split4(hv, zh[qq], zm[qq], zl[qq]);
+                    }
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 0) * 1024 + ln * 16) = make_uint4(zh[0].x, zh[0].y, zh[1].x, zh[1].y);
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 1) * 1024 + ln * 16) = make_uint4(zm[0].x, zm[0].y, zm[1].x, zm[1].y);
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 2) * 1024 + ln * 16) = make_uint4(zl[0].x, zl[0].y, zl[1].x, zl[1].y);
+                }
+            }
+        }
+        constexpr int RD = 6;
+        static_assert(KS % (RD / 3) == 0, "ring rounds");
+        uint4 ring[RD];
+        {
+            unsigned lo = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int q = 0; q < RD; ++q) ring[q] = *reinterpret_cast<const uint4*>(w2s + (lo + (unsigned)q * 1024u));
+        }
+        {
+            const int64_t gn = ((g + gridDim.x) * T < a.B) ? g + gridDim.x : g;
+            unsigned ln2 = (unsigned)lane;
+            asm volatile("" : "+v"(ln2));
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int64_t t = tile_of(gn, i);
+                load_x(i, x_by_tile ? t : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[t]), ln2);
+            }
+        }
+        __syncthreads();                                                // (1) every layer-1 tile of the T states is in LDS
+        // ================= layer 2
+        {
+            X6F_LANE();
+            f32x16 acc[T], accs[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = sB2[(w * 2 + h) * 4 + q];
+                    acc[i][4 * q + 0] = b.x; acc[i][4 * q + 1] = b.y; acc[i][4 * q + 2] = b.z; acc[i][4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[i][r] = 0.0f;
+            }
+            const unsigned lo16 = ln * 16u;
+            const char* zp = frag + lo16;
+            const char* wn = w2s + (size_t)RD * 1024;
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS; k0 += RD / 3) {
+#pragma unroll
+                for (int u = 0; u < RD / 3; ++u) {
+                    const uint4 wl = ring[3 * u + 0], wm = ring[3 * u + 1], wh = ring[3 * u + 2];
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+                        const char* zi = zp + (size_t)i * NT * 6 * 1024;
+                        const uint4 z_h = *reinterpret_cast<const uint4*>(zi + (u * 3 + 0) * 1024);
+                        const uint4 z_m = *reinterpret_cast<const uint4*>(zi + (u * 3 + 1) * 1024);
+                        const uint4 z_l = *reinterpret_cast<const uint4*>(zi + (u * 3 + 2) * 1024);
+                        accs[i] = x_mfma(wl, z_h, accs[i]);
+                        accs[i] = x_mfma(wm, z_m, accs[i]);
+                        accs[i] = x_mfma(wm, z_h, accs[i]);
+                        accs[i] = x_mfma(wh, z_l, accs[i]);
+                        accs[i] = x_mfma(wh, z_m, accs[i]);
+                        acc[i] = x_mfma(wh, z_h, acc[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    wn += 3 * 1024;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                zp += (RD / 3) * 3 * 1024;
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] + accs[i][r];
+                asm volatile("" : "+v"(acc[i]));
+                lrelu16(acc[i]);
+                const int64_t tile = g * T + i;
+                if (tile < a.B) {
+                    float4* dst = a.act2 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        typedef float f32x4l __attribute__((ext_vector_type(4)));
+                        const f32x4l t = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+                    }
+                }
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                const float4* w3 = sW3p + (h * NT + w) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 wv = w3[r];
+                    p0 = fmaf(wv.x, acc[i][r], p0); p1 = fmaf(wv.y, acc[i][r], p1);
+                    p2 = fmaf(wv.z, acc[i][r], p2); p3 = fmaf(wv.w, acc[i][r], p3);
+                }
+                sP[(i * NT + w) * 64 + ln] = make_float4(p0, p1, p2, p3);
+            }
+        }
+        __syncthreads();                                                // (2) partial logits in LDS; the H1 fragments are free
+        if (w < T && g * T + w < a.B) {                                 // wave i runs the loss tail of tile i
+            X6F_LANE();
+            const int64_t tile = g * T + w;
+            const int32_t sidw = __builtin_amdgcn_readfirstlane(a.idx[tile]);
+            const uint32_t act = a.active[sidw];
+            const float4* sPi = sP + (size_t)w * NT * 64;
+            float4 s = sPi[ln];
+#pragma unroll
+            for (int u = 1; u < NT; ++u) { const float4 q4 = sPi[u * 64 + ln]; s.x += q4.x; s.y += q4.y; s.z += q4.z; s.w += q4.w; }
+            float l[1][4];
+            l[0][0] = (s.x + __shfl_xor(s.x, 32)) + a.b3[0];
+            l[0][1] = (s.y + __shfl_xor(s.y, 32)) + a.b3[1];
+            l[0][2] = (s.z + __shfl_xor(s.z, 32)) + a.b3[2];
+            l[0][3] = (s.w + __shfl_xor(s.w, 32)) + a.b3[3];
+            policy_tail<2, 1, false>(a, tile, sidw, act, l, (int)ln, j, h);
+        }
+    }
+}
+
 // minibatches of up to this many 32-row tiles take the split-fp32 train forward (when ppo_set_bwd_split_bf16 is on);
 // PPO_FWD_SPLIT_MAX_TILES overrides (0 = never)
 #ifndef PPO_FWD_X6_DEFAULT_MAX_TILES
 #define PPO_FWD_X6_DEFAULT_MAX_TILES (1 << 30)
 #endif
+// HID = 256 minibatches of at least this many tiles take the two-tiles-per-pass form (PPO_FWD_SPLIT_T2_MIN_TILES; 0 = never)
+#ifndef PPO_FWD_X6_T2_DEFAULT_MIN_TILES
+#define PPO_FWD_X6_T2_DEFAULT_MIN_TILES 1536
+#endif
+static int64_t g_fwd_x6_t2_min_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_T2_DEFAULT_MIN_TILES; }();
 static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_DEFAULT_MAX_TILES; }();
 
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
@@ -272,7 +516,20 @@ int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int t
         hipLaunchKernelGGL((k_policy_fwd_train_x6<HH>), dim3(nwg), dim3(HH * 2), lds, ppo_stream(), a,       \
                            (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);                                 \
     } while (0)
-    if (p->HID == 256) LAUNCH(256);
+    if (p->HID == 256 && g_fwd_x6_t2_min_tiles > 0 && B >= g_fwd_x6_t2_min_tiles) {
+        constexpr int T = 2;
+        const int64_t groups = (B + T - 1) / T;
+        const int nwg = (int)(groups < 256 ? groups : 256);
+        const size_t lds = FXTCfg<256, T>::total;
+        static thread_local bool attr_set2 = false;
+        if (!attr_set2) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_x6t<256, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL((k_policy_fwd_train_x6t<256, T>), dim3(nwg), dim3(512), lds, ppo_stream(), a,
+                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);
+    }
+    else if (p->HID == 256) LAUNCH(256);
     else if (p->HID == 128) LAUNCH(128);
     else return PPO_ERR_UNSUPPORTED;
 #undef LAUNCH
