@@ -349,6 +349,8 @@ def main():
     if use_dist:
         PPO._lib.call("ppo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
+    if args.stream:
+        PPO.set_disk_async(os.environ.get("PPO_DISK_ASYNC", "1") != "0")     # deferred finish of the streamed file
     dp = PPO.DataParallel(rank, world, force_hook=use_dist)
     pol = PPO.HipPolicy(F, HID, LAYERS, 4, seed=0, dtype=args.dtype)
     opt = PPO.Optimiser(PPO.Adam(LR))
@@ -364,16 +366,20 @@ def main():
         """W warm-up + K timed PPO iterations on `n_envs` envs per rank; returns (max-over-ranks seconds, iteration fn)."""
         env = PPO.HipVecEnv(num_envs=n_envs, Q=QUADS, max_actions=T_STEPS, seed=1234, global_offset=rank * n_envs)
         ro = PPO.BufferRollouts()
+        stream_pending = []
 
         def iteration(i):
             if args.stream:                              # a fresh DiskRollouts per iteration, as src/train.jl:185 does
                 dro = PPO.DiskRollouts(os.path.join(args.stream, "rank%d" % rank))
                 PPO.collect_rollouts_steps_(dro, env, pol, T_STEPS, GAMMA)
                 ds = PPO.construct_dataset(dro._device)
+                stream_pending.append(dro)
             else:
                 PPO.collect_rollouts_steps_(ro, env, pol, T_STEPS, GAMMA)
                 ds = PPO.construct_dataset(ro)
             PPO.ppo_train_(pol, opt, ds, EPS, minibatch, EPOCHS, ENT_W, seed=seed_base + i, parallel=dp, verbose=False)
+            while stream_pending:                        # deferred finish (PPO_DISK_ASYNC=1): the file of THIS iteration is complete
+                PPO.disk_sync(stream_pending.pop())      # before the iteration counts as done (inside the timed region)
 
         for i in range(args.warmup):
             iteration(i)

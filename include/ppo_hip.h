@@ -303,6 +303,14 @@ int32_t ppo_rccl_finalize(void);
  * attach wipes and recreates <dir> like the DiskRollouts constructor (:7-13,23-45). */
 int32_t ppo_rollouts_attach_disk(ppo_rollouts_t ro, const char* dir, int32_t pinned_slots);
 int32_t ppo_rollouts_detach_disk(ppo_rollouts_t ro);
+/* Deferred finish of a streamed collection.  ppo_set_disk_async(1) (PPO_DISK_ASYNC=1; default 0): the pinned ring is sized to
+ * hold EVERY step of the collection (up to PPO_DISK_ASYNC_MAX_BYTES, default 1 GiB), ppo_collect_rollouts returns as soon as the
+ * last step and the returns column are on the copy stream, and the writer thread finishes <dir>/rollout.bin on its own while
+ * the caller trains on the columns that stayed in HBM.  The file is complete when ppo_rollouts_disk_sync returns (the next
+ * collection into the same buffer, detach and destroy wait for it too).  With mode 0 the file is complete when
+ * ppo_collect_rollouts returns, as before (the reference's rollouts_to_disk is synchronous: src/rollouts_to_disk.jl:73-132). */
+int32_t ppo_set_disk_async(int32_t mode);
+int32_t ppo_rollouts_disk_sync(ppo_rollouts_t ro);
 /* DiskDataset: read <dir>/rollout.bin back into the (device) rollout buffer; shapes must match the env it was
  * created for.  All transitions are valid afterwards. */
 int32_t ppo_rollouts_load_disk(ppo_rollouts_t ro, const char* dir);

@@ -697,7 +697,8 @@ def collect_rollouts_steps_(rollouts, env, policy, num_steps, discount, record_p
         call("ppo_rollouts_attach_disk", h, rollouts.state_data_directory.encode(), int(pinned_slots))
         g, f32 = _discount_args(discount)
         call("ppo_collect_rollouts", h, env._h, policy._h, int(num_steps), g, f32, 0)
-        call("ppo_rollouts_detach_disk", h)
+        if not _DISK_ASYNC[0]:
+            call("ppo_rollouts_detach_disk", h)      # (deferred finish: disk_sync detaches once the file is complete)
         rollouts._device = dev
         rollouts.num_samples = len(dev)
         with open(rollouts.trajectory_filename, "w", newline="") as f:          # attach wiped it: keep the header
@@ -792,6 +793,26 @@ def construct_dataset(rollouts):
             return BufferDataset(rollouts._device)       # columns are still resident: no reload needed
         return DiskDataset(rollouts.state_data_directory)
     return BufferDataset(rollouts)
+
+
+def set_disk_async(on=None):
+    """Streamed collections (DiskRollouts) return without waiting for the file: the pinned ring holds the whole collection and
+    the writer thread finishes rollout.bin while training runs; disk_sync(rollouts) (or the next collection) waits for it.
+    None / False = the file is complete when collect_rollouts_ returns (default, the reference's behaviour)."""
+    call("ppo_set_disk_async", -1 if on is None else int(bool(on)))
+    _DISK_ASYNC[0] = bool(on)
+
+
+_DISK_ASYNC = [False]
+
+
+def disk_sync(rollouts):
+    """Wait until the rollout file of a streamed collection is complete, then detach the store (only needed after
+    set_disk_async(True); a no-op otherwise)."""
+    dev = getattr(rollouts, "_device", None) or rollouts
+    if getattr(dev, "_h", None):
+        call("ppo_rollouts_disk_sync", dev._h)
+        call("ppo_rollouts_detach_disk", dev._h)
 
 
 def load_disk_rollouts(state_data_dir, env):

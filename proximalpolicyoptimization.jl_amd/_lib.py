@@ -97,6 +97,8 @@ SIGNATURES = {
                   C.c_int32, ALLREDUCE_FN, C.c_void_p, c_f64p, c_f64p, c_f64p],
     "ppo_rollouts_attach_disk": [H, C.c_char_p, C.c_int32],
     "ppo_rollouts_detach_disk": [H],
+    "ppo_set_disk_async": [C.c_int32],
+    "ppo_rollouts_disk_sync": [H],
     "ppo_rollouts_load_disk": [H, C.c_char_p],
     "ppo_average_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],
     "ppo_average_best_returns": [H, H, H, C.c_int64, c_f64p, c_f64p],

@@ -641,7 +641,7 @@ int32_t ppo_collect_rollouts(ppo_rollouts_t ro, ppo_env_t env, ppo_policy_t pol,
     PPO_TRY(disk_sink_begin(ro, T));
     if (persistent_ok && !ro->sink) ps = launch_policy_rollout_persistent(pol, env, ro, T, record_probs);
     else if (persistent_ok) {
-        const int64_t chunk = std::max(1, disk_sink_slots(ro) / 2);        // half the ring in flight, half draining
+        const int64_t chunk = disk_sink_chunk(ro);                         // half the ring in flight (at most 8 steps), the rest draining
         for (int64_t t0 = 0; t0 < T; t0 += chunk) {
             const int64_t tc = std::min(chunk, T - t0);
             ps = launch_policy_rollout_persistent(pol, env, ro, tc, record_probs, t0);

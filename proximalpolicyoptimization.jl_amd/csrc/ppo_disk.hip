@@ -41,7 +41,7 @@ static int32_t template_hash(const ppo_rollouts_s* ro, uint64_t* out) {
 
 struct DiskSink {
     std::string dir;
-    int slots = 0;
+    int slots = 0, slots0 = 0;            // ring size now / as attached (the deferred-finish mode grows it per collection)
     size_t rec_bytes = 0;
     std::vector<char*> pinned;            // ring of pinned host records
     std::vector<hipEvent_t> produced;     // recorded on the compute stream after step t's kernels
@@ -54,7 +54,21 @@ struct DiskSink {
     int64_t enq = 0, written = 0;         // records handed to the copy stream / written to the file
     int batch = 1;                        // records per writev()
     bool stop = false, failed = false;
+    // deferred finish (ppo_set_disk_async): the ring holds the whole collection, ppo_collect_rollouts returns as soon as the
+    // last step is on the copy stream, and the writer thread appends the returns column and closes the file by itself
+    bool async_fin = false;               // this collection finishes in the writer thread
+    bool fin_pending = false, fin_done = false;
+    int64_t T_total = 0;
+    char* ret_pinned = nullptr; size_t ret_bytes = 0;
+    hipEvent_t ret_ready = nullptr, ret_copied = nullptr;
 };
+
+// ppo_set_disk_async / PPO_DISK_ASYNC: 1 = a streamed collection returns without waiting for the file (ppo_rollouts_disk_sync,
+// the next collection, detach and destroy wait for it); the pinned ring then holds every step of the collection when
+// that fits PPO_DISK_ASYNC_MAX_BYTES (default 1 GiB), so the disk never holds the collection back
+static int g_disk_async = [] { const char* v = getenv("PPO_DISK_ASYNC"); return v ? atoi(v) != 0 : 0; }();
+extern "C" int32_t ppo_set_disk_async(int32_t mode) { g_disk_async = mode < 0 ? 0 : (mode != 0); return PPO_OK; }
+static size_t disk_async_budget() { const char* v = getenv("PPO_DISK_ASYNC_MAX_BYTES"); return v ? (size_t)atoll(v) : ((size_t)1 << 30); }
 
 // Process-wide pool of pinned records: the reference creates a fresh DiskRollouts every PPO iteration
 // (src/train.jl:185), and hipHostMalloc / hipHostFree of the ring cost more than streaming a short rollout.
@@ -115,8 +129,23 @@ static void writer_loop(DiskSink* s) {
         int64_t k, avail;
         {
             std::unique_lock<std::mutex> lk(s->mu);
-            s->cv.wait(lk, [&] { return s->stop || s->written < s->enq; });
-            if (s->written >= s->enq) { if (s->stop) return; continue; }
+            s->cv.wait(lk, [&] { return s->stop || s->written < s->enq || (s->fin_pending && !s->fin_done); });
+            if (s->written >= s->enq) {
+                if (s->fin_pending && !s->fin_done && s->written >= s->T_total) {
+                    // deferred finish: the returns column (copied device -> pinned behind the return scan), then close
+                    lk.unlock();
+                    bool ok = !s->failed && hipEventSynchronize(s->ret_copied) == hipSuccess;
+                    if (ok) { struct iovec v; v.iov_base = s->ret_pinned; v.iov_len = s->ret_bytes; ok = write_all(fd, &v, 1); }
+                    lk.lock();
+                    if (!ok) s->failed = true;
+                    s->fin_done = true;
+                    lk.unlock();
+                    s->cv.notify_all();
+                    continue;
+                }
+                if (s->stop) return;
+                continue;
+            }
             k = s->written; avail = s->enq - s->written;
         }
         const int nb = (int)std::min<int64_t>(avail, maxb);
@@ -134,18 +163,34 @@ static void writer_loop(DiskSink* s) {
     }
 }
 
-void disk_sink_destroy(DiskSink* s) {
-    if (!s) return;
+// a deferred finish is complete (or has failed) when this returns; the writer thread is stopped and the file closed
+static bool disk_sink_settle(DiskSink* s) {
+    bool ok = true;
     if (s->writer.joinable()) {
-        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            if (s->fin_pending) s->cv.wait(lk, [&] { return s->fin_done || s->failed; });
+            s->stop = true;
+        }
         s->cv.notify_all();
         s->writer.join();
     }
+    if (s->fin_pending) { ok = !s->failed && s->fin_done; s->fin_pending = false; }
+    if (s->f) { if (fclose(s->f) != 0) ok = false; s->f = nullptr; }
+    return ok;
+}
+
+void disk_sink_destroy(DiskSink* s) {
+    if (!s) return;
+    (void)disk_sink_settle(s);
     if (s->f) fclose(s->f);
     // a device -> host copy may still be in flight into a record (error / early-detach paths): the records go back to a
     // process-wide pool, so nobody else may receive one before the copy stream has drained
     if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     for (char* p : s->pinned) pinned_put(s->rec_bytes, p);
+    pinned_put(s->ret_bytes, s->ret_pinned);
+    if (s->ret_ready) (void)hipEventDestroy(s->ret_ready);
+    if (s->ret_copied) (void)hipEventDestroy(s->ret_copied);
     for (auto e : s->produced) (void)hipEventDestroy(e);
     for (auto e : s->copied) (void)hipEventDestroy(e);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
@@ -194,19 +239,44 @@ extern "C" int32_t ppo_rollouts_detach_disk(ppo_rollouts_t ro) {
 }
 
 int disk_sink_slots(const ppo_rollouts_s* ro) { return ro->sink ? ro->sink->slots : 0; }
+// steps per persistent launch of a streamed collection: half the ring in flight, at most 8 (finer D2H / launch overlap)
+int disk_sink_chunk(const ppo_rollouts_s* ro) { return ro->sink ? std::max(1, std::min(ro->sink->slots / 2, 8)) : 0; }
+
+extern "C" int32_t ppo_rollouts_disk_sync(ppo_rollouts_t ro) {
+    ARG_CHECK(ro, "null");
+    if (!ro->sink) return PPO_OK;
+    if (!disk_sink_settle(ro->sink)) { ppo_set_error("DiskRollouts: writer failed (disk full?)"); return PPO_ERR_ARG; }
+    return PPO_OK;
+}
 
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     DiskSink* s = ro->sink;
     if (!s) return PPO_OK;
-    if (s->writer.joinable()) {                       // a previous collection: restart the file
-        { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
-        s->cv.notify_all();
-        s->writer.join();
-    }
-    if (s->f) { fclose(s->f); s->f = nullptr; }
-    s->enq = s->written = 0; s->stop = false; s->failed = false;
+    (void)disk_sink_settle(s);                        // a previous collection (its deferred finish included): restart the file
+    s->enq = s->written = 0; s->stop = false; s->failed = false; s->fin_pending = s->fin_done = false;
     const size_t rec = record_bytes(ro, ro->compact);           // the storage form is decided per collection
     if (s->copy_stream) HIP_TRY(hipStreamSynchronize(s->copy_stream));   // nothing of a previous collection is still landing
+    s->async_fin = g_disk_async != 0;
+    s->T_total = T;
+    int want_slots = s->slots0 ? s->slots0 : s->slots;
+    if (!s->slots0) s->slots0 = s->slots;
+    if (s->async_fin) {                                         // the whole collection in the ring when the budget allows
+        const int64_t fit = (int64_t)(disk_async_budget() / (rec ? rec : 1));
+        want_slots = (int)std::max<int64_t>(s->slots0, std::min<int64_t>(T, std::max<int64_t>(fit, 2)));
+    }
+    if (want_slots != s->slots) {
+        for (char*& p : s->pinned) { pinned_put(s->rec_bytes, p); p = nullptr; }
+        s->rec_bytes = 0;
+        for (auto e : s->produced) (void)hipEventDestroy(e);
+        for (auto e : s->copied) (void)hipEventDestroy(e);
+        s->slots = want_slots;
+        s->pinned.assign(want_slots, nullptr);
+        s->produced.assign(want_slots, nullptr); s->copied.assign(want_slots, nullptr);
+        for (int i = 0; i < want_slots; ++i) {
+            (void)hipEventCreateWithFlags(&s->produced[i], hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming);
+        }
+    }
     if (rec != s->rec_bytes) {
         for (char*& p : s->pinned) { pinned_put(s->rec_bytes, p); p = nullptr; }
         s->rec_bytes = rec;
@@ -238,7 +308,7 @@ int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T) {
     // flushed here and holds nothing in between.  Blocks reserved up front where the file system can (no per-call
     // allocation; KEEP_SIZE: the file still grows by appending, a short collection leaves no zero tail)
     (void)fallocate(fileno(s->f), FALLOC_FL_KEEP_SIZE, 0, (off_t)(hdr_bytes + (size_t)T * rec + (size_t)T * ro->N * 4));
-    s->batch = std::max(1, s->slots / 2);
+    s->batch = std::max(1, std::min(s->slots / 2, 8));
     if (const char* e = getenv("PPO_DISK_BATCH")) s->batch = std::max(1, std::min(s->slots, atoi(e)));
     s->writer = std::thread(writer_loop, s);
     return PPO_OK;
@@ -272,6 +342,24 @@ int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t) {
 int32_t disk_sink_finish(ppo_rollouts_s* ro) {
     DiskSink* s = ro->sink;
     if (!s) return PPO_OK;
+    if (s->async_fin) {
+        // deferred finish: the returns column goes device -> pinned on the copy stream behind the return scan; the writer
+        // thread appends it after the last record and closes the file (ppo_rollouts_disk_sync waits for that)
+        const size_t nb = (size_t)ro->T * ro->N * 4;
+        if (nb != s->ret_bytes) {
+            pinned_put(s->ret_bytes, s->ret_pinned);
+            s->ret_pinned = pinned_get(nb); s->ret_bytes = s->ret_pinned ? nb : 0;
+            if (!s->ret_pinned) { ppo_set_error("DiskRollouts: pinned allocation failed (returns column)"); return PPO_ERR_HIP; }
+        }
+        if (!s->ret_ready) { HIP_TRY(hipEventCreateWithFlags(&s->ret_ready, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&s->ret_copied, hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(s->ret_ready, ppo_stream()));
+        HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ret_ready, 0));
+        HIP_TRY(hipMemcpyAsync(s->ret_pinned, ro->returns.p, nb, hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_TRY(hipEventRecord(s->ret_copied, s->copy_stream));
+        { std::lock_guard<std::mutex> lk(s->mu); s->T_total = ro->T; s->fin_pending = true; }
+        s->cv.notify_all();
+        return PPO_OK;
+    }
     {   // drain the ring
         std::unique_lock<std::mutex> lk(s->mu);
         s->cv.wait(lk, [&] { return s->failed || s->written >= s->enq; });

@@ -176,6 +176,7 @@ extern "C" int32_t set_index_all(ppo_rollouts_s* r);
 // out-of-core store hooks used by ppo_collect_rollouts (ppo_disk.hip)
 int32_t disk_sink_begin(ppo_rollouts_s* ro, int64_t T);
 int disk_sink_slots(const ppo_rollouts_s* ro);                // pinned records in the ring (0: no sink)
+int disk_sink_chunk(const ppo_rollouts_s* ro);                // steps per persistent launch of a streamed collection
 int32_t disk_sink_step(ppo_rollouts_s* ro, int64_t t);       // after the kernels of step t were enqueued
 int32_t disk_sink_finish(ppo_rollouts_s* ro);                // after the return scan: appends returns, flushes
 void disk_sink_destroy(DiskSink* s);

@@ -435,6 +435,8 @@ def test_rollout_bitexact_fuzz(P, orc, case, rollout_mode):
 @pytest.mark.parametrize("B", [1, 2, 3, 31, 33, 255, 257])
 def test_gradient_ragged_batch_sizes(P, orc, B, bwd_form):
     """Minibatches that do not fill the persistent grid (B = 1 ... 257 tiles on 256 workgroups) and repeat samples."""
+    if bwd_form == -2 and B not in (1, 257):
+        pytest.skip("the fp32-MFMA form of the large-minibatch kernels: the two ends of the range only (suite time)")
     env, pol, ro, ds = _make_dataset(P, orc, 30, 10, 256, seed=77)      # 300 samples
     rng = np.random.default_rng(B)
     sel = rng.integers(1, len(ds) + 1, size=B)
