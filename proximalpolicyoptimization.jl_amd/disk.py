@@ -133,6 +133,20 @@ def _fmt32(x):
 
 
 # ------------------------------------------------------------------ DiskRollouts (host-side, reference layout)
+def _wipe(path):
+    """rm -rf `path` as the reference does before every collection -- but the unlink of the previous iteration's shard (0.7 GB
+    at 65,536 envs: 50-75 ms of file-system work) happens on a helper thread: the directory is renamed aside first, so the
+    caller sees it gone at once."""
+    import threading
+    aside = "%s.wipe-%d-%d" % (path.rstrip("/"), os.getpid(), threading.get_ident() ^ id(path))
+    try:
+        os.rename(path, aside)
+    except OSError:
+        shutil.rmtree(path)
+        return
+    threading.Thread(target=shutil.rmtree, args=(aside,), kwargs={"ignore_errors": True}, daemon=False).start()
+
+
 class DiskRollouts:
     """PPO.DiskRollouts(state_data_dir) (src/rollouts_to_disk.jl:23-45): wipes the directory, creates states/,
     starts trajectory.csv with the five-column header."""
@@ -143,7 +157,7 @@ class DiskRollouts:
         self.state_data_directory = state_data_dir
         self.num_samples = 0
         if os.path.isdir(state_data_dir):                          # prepare_state_data_directory :7-13
-            shutil.rmtree(state_data_dir)
+            _wipe(state_data_dir)
         os.makedirs(os.path.join(state_data_dir, "states"))
         self.trajectory_filename = os.path.join(state_data_dir, "trajectory.csv")
         with open(self.trajectory_filename, "w", newline="") as f:
