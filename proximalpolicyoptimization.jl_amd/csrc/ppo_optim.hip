@@ -44,7 +44,15 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
     // fixed summation order: 8 interleaved partial sums per slab group, a fixed tree, then the 4 groups in order
     float ps[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nwg = (e < nW2 + nW1) ? nwg_w : nwg_s;
-    if (e < total) {
+    // padding columns of the dW1 block (inputs F .. FP-1: a quarter of its last 32-column tile for F = 72) map to no parameter:
+    // their slab values are never read (the split-fp32 backward does not write them either, except the ones column it keeps db1 in)
+    bool dead = false;
+    if (e >= nW2 && e < nW2 + nW1) {
+        const size_t e1 = e - nW2;
+        const int it = (int)((e1 >> 10) % L.NI);
+        dead = 32 * it + (int)(e1 & 31) >= L.F;
+    }
+    if (e < total && !dead) {
         int g = grp;
         for (; g + 28 < nwg; g += 32) {
 #pragma unroll

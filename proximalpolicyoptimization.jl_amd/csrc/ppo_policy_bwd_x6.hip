@@ -505,9 +505,11 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW2[((size_t)(w * NT + kt) * 16 + r) * 64 + lane] = accW2[kt][r];
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
+    for (int it = 0; it < NI; ++it) {
+        if (32 * it + j >= F) continue;                 // padding columns (inputs 72 .. 95): k_grad_reduce never reads them
 #pragma unroll
         for (int r = 0; r < 16; ++r) sW1[((size_t)(w * NI + it) * 16 + r) * 64 + lane] = accW1[it][r];
+    }
     // db1[k] = dW1[k][input 72] (the ones column): column 8 of input tile 2, held by lanes 8 and 40
     if (j == F - 64) {
 #pragma unroll
