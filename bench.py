@@ -486,7 +486,7 @@ def main():
             for name, ratio in (("k_policy_bwd", split_backward_mfma_flops_per_state() / flops_per_state("bwd")),
                                 ("k_policy_fwd_train", 2 * rows * (3 * HID * 80 + 6 * HID * HID) / flops_per_state("fwd"))):
                 kk = kernels.get(name)
-                if not kk or (name == "k_policy_fwd_train" and (QUADS != 8 or os.environ.get("PPO_FWD_SPLIT_MAX_TILES") == "0")):
+                if not kk or (name == "k_policy_fwd_train" and ((QUADS == 32 and HID != 256) or os.environ.get("PPO_FWD_SPLIT_MAX_TILES") == "0")):
                     continue
                 kk["executed_bf16_mfma_tflops"] = round(kk["tflops"] * ratio, 1)
                 kk["frac"] = round(kk["tflops"] * ratio / PEAK_BF16_MFMA_TFLOPS, 4)       # of the pipe that bounds it

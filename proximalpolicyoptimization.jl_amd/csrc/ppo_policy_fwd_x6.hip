@@ -480,6 +480,244 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
     }
 }
 
+template <int HID, int TPS>
+struct FXSCfg {                                   // H1 fragments of the two tiles of a pass, partial logits of all TPS tiles
+    static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;
+    static constexpr size_t oFr = 0, szFr = (size_t)2 * NT * 6 * 1024;
+    static constexpr size_t oP = oFr + szFr, oW3 = oP + (size_t)TPS * NT * 1024, oB1 = oW3 + (size_t)2 * NT * 256,
+                            oB2 = oB1 + (size_t)NT * 128, total = oB2 + (size_t)NT * 128;
+    static_assert(total <= 160 * 1024, "LDS budget");
+};
+
+// ---------------------------------------------------------------- states of TPS tiles (H = 32 TPS half-edges: Q = 32 -> TPS = 4)
+// One workgroup per STATE: its TPS tiles go through both layers two at a time (TPS / 2 passes over the weight stream), the
+// layer-3 partial dots of all tiles wait in LDS, then wave 0 runs the state's loss tail over its 128 TPS actions.
+template <int HID, int TPS>
+__global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6s(FwdArgs a, const uint4* __restrict__ w1x, const uint4* __restrict__ w2fx, int x_by_tile) {
+    constexpr int T = 2;
+    static_assert(TPS % T == 0, "tiles of a state in pairs");
+    using C = FXSCfg<HID, TPS>;
+    constexpr int F = C::F, NT = C::NT, KS = C::KS, K1 = C::K1;
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    char* const frag = smem_c + C::oFr;                                    // [T][feature tile][k-step 2][piece 3][64 lanes][16 B]
+    float4* const sP = reinterpret_cast<float4*>(smem_c + C::oP);          // [T][NT][64] layer-3 partial dots
+    float4* const sW3p = reinterpret_cast<float4*>(smem_c + C::oW3);
+    float4* const sB1 = reinterpret_cast<float4*>(smem_c + C::oB1);
+    float4* const sB2 = reinterpret_cast<float4*>(smem_c + C::oB2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * NT * 16; i += NT * 64) sW3p[i] = a.w3p[i];
+    for (int i = tid; i < NT * 8; i += NT * 64) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
+    __syncthreads();
+    const char* const w1s = reinterpret_cast<const char*>(w1x + (size_t)w * K1 * 3 * 64);
+    const char* const w2s = reinterpret_cast<const char*>(w2fx + (size_t)w * KS * 3 * 64);
+
+    uint2 xr[T][K1];
+    auto load_x = [&](int i, int64_t rec, unsigned ln) {
+        const char* row = reinterpret_cast<const char*>(a.states) + (size_t)rec * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+            const bool pad = (s == K1 - 1) && (ln >> 5);
+            const uint2 v = *reinterpret_cast<const uint2*>(row + (pad ? 0 : 16 * s));
+            xr[i][s] = pad ? make_uint2(0u, 0u) : v;
+        }
+    };
+    // pass q = state * (TPS / T) + p covers tiles ts = p*T + i of its state; the record of tile (state, ts) is state*TPS + ts
+    constexpr int NP = TPS / T;
+    auto rec_of = [&](int64_t state, int ts) {
+        return (x_by_tile ? state : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[state])) * TPS + ts;
+    };
+    if ((int64_t)blockIdx.x < a.B) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) load_x(i, rec_of(blockIdx.x, i), (unsigned)lane);
+    }
+    for (int64_t st8 = blockIdx.x; st8 < a.B; st8 += gridDim.x) {
+    for (int p = 0; p < NP; ++p) {
+        const int64_t g = st8 * NP + p;                                 // global pass index: tiles g*T + i
+        // ================= layer 1: H1 tile w of the T states
+        {
+            X6F_LANE();
+            unsigned lo16 = ln * 16u;
+            constexpr int R1 = 8;
+            uint4 ring[R1];
+#pragma unroll
+            for (int q = 0; q < R1; ++q) ring[q] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)q * 1024u));
+            f32x16 acc[T], accs[T];
+            uint4 xb[T][K1];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = sB1[(w * 2 + h) * 4 + q];
+                    acc[i][4 * q + 0] = b.x; acc[i][4 * q + 1] = b.y; acc[i][4 * q + 2] = b.z; acc[i][4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[i][r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < K1; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)(int)(int8_t)((e < 4 ? xr[i][s].x : xr[i][s].y) >> (8 * (e & 3)));
+                    xb[i][s] = make_uint4(x_perm(v[0], v[1]), x_perm(v[2], v[3]), x_perm(v[4], v[5]), x_perm(v[6], v[7]));
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 3 * K1; ++st) {
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (st % 3 == 2) acc[i] = x_mfma(ring[st % R1], xb[i][st / 3], acc[i]);
+                    else accs[i] = x_mfma(ring[st % R1], xb[i][st / 3], accs[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + R1 < 3 * K1) ring[st % R1] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)(st + R1) * 1024u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] + accs[i][r];
+                asm volatile("" : "+v"(acc[i]));
+                lrelu16(acc[i]);
+                const int64_t tile = g * T + i;
+                {
+                    float4* dst = a.act1 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        typedef float f32x4l __attribute__((ext_vector_type(4)));
+                        const f32x4l t = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+                    }
+                }
+                char* const fown = frag + ((size_t)i * NT + w) * 6 * 1024;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    uint2 zh[2], zm[2], zl[2];
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int q = 2 * s + qq;
+                        const float hv[4] = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        x_split4(hv, zh[qq], zm[qq], zl[qq]);
+                    }
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 0) * 1024 + ln * 16) = make_uint4(zh[0].x, zh[0].y, zh[1].x, zh[1].y);
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 1) * 1024 + ln * 16) = make_uint4(zm[0].x, zm[0].y, zm[1].x, zm[1].y);
+                    *reinterpret_cast<uint4*>(fown + (s * 3 + 2) * 1024 + ln * 16) = make_uint4(zl[0].x, zl[0].y, zl[1].x, zl[1].y);
+                }
+            }
+        }
+        constexpr int RD = 6;
+        static_assert(KS % (RD / 3) == 0, "ring rounds");
+        uint4 ring[RD];
+        {
+            unsigned lo = (unsigned)lane * 16u;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            for (int q = 0; q < RD; ++q) ring[q] = *reinterpret_cast<const uint4*>(w2s + (lo + (unsigned)q * 1024u));
+        }
+        {
+            // the next pass: the state's next pair of tiles, or the first pair of this workgroup's next state (the last pass re-loads itself)
+            const bool more = p + 1 < NP;
+            const int64_t sn = more ? st8 : (st8 + gridDim.x < a.B ? st8 + gridDim.x : st8);
+            const int pn = more ? p + 1 : (st8 + gridDim.x < a.B ? 0 : p);
+            unsigned ln2 = (unsigned)lane;
+            asm volatile("" : "+v"(ln2));
+#pragma unroll
+            for (int i = 0; i < T; ++i) load_x(i, rec_of(sn, pn * T + i), ln2);
+        }
+        __syncthreads();                                                // (1) every layer-1 tile of the T states is in LDS
+        // ================= layer 2
+        {
+            X6F_LANE();
+            f32x16 acc[T], accs[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = sB2[(w * 2 + h) * 4 + q];
+                    acc[i][4 * q + 0] = b.x; acc[i][4 * q + 1] = b.y; acc[i][4 * q + 2] = b.z; acc[i][4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[i][r] = 0.0f;
+            }
+            const unsigned lo16 = ln * 16u;
+            const char* zp = frag + lo16;
+            const char* wn = w2s + (size_t)RD * 1024;
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS; k0 += RD / 3) {
+#pragma unroll
+                for (int u = 0; u < RD / 3; ++u) {
+                    const uint4 wl = ring[3 * u + 0], wm = ring[3 * u + 1], wh = ring[3 * u + 2];
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+                        const char* zi = zp + (size_t)i * NT * 6 * 1024;
+                        const uint4 z_h = *reinterpret_cast<const uint4*>(zi + (u * 3 + 0) * 1024);
+                        const uint4 z_m = *reinterpret_cast<const uint4*>(zi + (u * 3 + 1) * 1024);
+                        const uint4 z_l = *reinterpret_cast<const uint4*>(zi + (u * 3 + 2) * 1024);
+                        accs[i] = x_mfma(wl, z_h, accs[i]);
+                        accs[i] = x_mfma(wm, z_m, accs[i]);
+                        accs[i] = x_mfma(wm, z_h, accs[i]);
+                        accs[i] = x_mfma(wh, z_l, accs[i]);
+                        accs[i] = x_mfma(wh, z_m, accs[i]);
+                        acc[i] = x_mfma(wh, z_h, acc[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    wn += 3 * 1024;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                zp += (RD / 3) * 3 * 1024;
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] + accs[i][r];
+                asm volatile("" : "+v"(acc[i]));
+                lrelu16(acc[i]);
+                const int64_t tile = g * T + i;
+                {
+                    float4* dst = a.act2 + ((size_t)tile * NT + w) * 4 * 64;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        typedef float f32x4l __attribute__((ext_vector_type(4)));
+                        const f32x4l t = {acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]};
+                        __builtin_nontemporal_store(t, reinterpret_cast<f32x4l*>(dst + q * 64 + ln));
+                    }
+                }
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                const float4* w3 = sW3p + (h * NT + w) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float4 wv = w3[r];
+                    p0 = fmaf(wv.x, acc[i][r], p0); p1 = fmaf(wv.y, acc[i][r], p1);
+                    p2 = fmaf(wv.z, acc[i][r], p2); p3 = fmaf(wv.w, acc[i][r], p3);
+                }
+                sP[((p * T + i) * NT + w) * 64 + ln] = make_float4(p0, p1, p2, p3);
+            }
+        }
+        __syncthreads();                                                // (2) partial logits in LDS; the H1 fragments are free
+        if (p == NP - 1 && w == 0) {                                    // all tiles of the state are through: its loss tail
+            X6F_LANE();
+            const int32_t sidw = __builtin_amdgcn_readfirstlane(a.idx[st8]);
+            const uint32_t act = a.active[sidw];
+            float l[TPS][4];
+#pragma unroll
+            for (int ts = 0; ts < TPS; ++ts) {
+                const float4* sPi = sP + (size_t)ts * NT * 64;
+                float4 s = sPi[ln];
+#pragma unroll
+                for (int u = 1; u < NT; ++u) { const float4 q4 = sPi[u * 64 + ln]; s.x += q4.x; s.y += q4.y; s.z += q4.z; s.w += q4.w; }
+                l[ts][0] = (s.x + __shfl_xor(s.x, 32)) + a.b3[0];
+                l[ts][1] = (s.y + __shfl_xor(s.y, 32)) + a.b3[1];
+                l[ts][2] = (s.z + __shfl_xor(s.z, 32)) + a.b3[2];
+                l[ts][3] = (s.w + __shfl_xor(s.w, 32)) + a.b3[3];
+            }
+            policy_tail<2, TPS, false>(a, st8, sidw, act, l, (int)ln, j, h);
+        }
+    }
+    }
+}
+
 // minibatches of up to this many 32-row tiles take the split-fp32 train forward (when ppo_set_bwd_split_bf16 is on);
 // PPO_FWD_SPLIT_MAX_TILES overrides (0 = never)
 #ifndef PPO_FWD_X6_DEFAULT_MAX_TILES
@@ -494,7 +732,7 @@ static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SP
 
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
     if (!ppo_bwd_split_enabled() || B > g_fwd_x6_max_tiles) return PPO_ERR_UNSUPPORTED;
-    if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || tps != 1 || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
+    if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || !(tps == 1 || (tps == 4 && p->HID == 256)) || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
     if (compact) {
         // env snapshots: the minibatch's observation rows are re-derived first (the arithmetic of state(env), ppo_env.hip) into
         // the scratch the backward reads in this storage form anyway; both kernels then see the rows the expanded form holds,
@@ -516,7 +754,18 @@ int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int t
         hipLaunchKernelGGL((k_policy_fwd_train_x6<HH>), dim3(nwg), dim3(HH * 2), lds, ppo_stream(), a,       \
                            (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);                                 \
     } while (0)
-    if (p->HID == 256 && g_fwd_x6_t2_min_tiles > 0 && B >= g_fwd_x6_t2_min_tiles) {
+    if (tps == 4) {                                               // Q = 32 states: one workgroup per state, its four tiles in two passes
+        const int nwg = (int)(B < 256 ? B : 256);
+        const size_t lds = FXSCfg<256, 4>::total;
+        static thread_local bool attr_set4 = false;
+        if (!attr_set4) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_x6s<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set4 = true;
+        }
+        hipLaunchKernelGGL((k_policy_fwd_train_x6s<256, 4>), dim3(nwg), dim3(512), lds, ppo_stream(), a,
+                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);
+    }
+    else if (p->HID == 256 && g_fwd_x6_t2_min_tiles > 0 && B >= g_fwd_x6_t2_min_tiles) {
         constexpr int T = 2;
         const int64_t groups = (B + T - 1) / T;
         const int nwg = (int)(groups < 256 ? groups : 256);
