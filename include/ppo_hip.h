@@ -223,7 +223,9 @@ int32_t ppo_forward_backward(ppo_policy_t pol, ppo_rollouts_t ro, const int64_t*
 /* Which backward kernel a minibatch takes (same gradient, different reduction tree: results agree to fp32 rounding):
  * up to `tiles` 32-row tiles the three-product form (dZ kernel + output-stationary split-K weight-gradient kernel: no
  * per-workgroup gradient slabs, the fixed cost that dominates a small optimiser step), above it the fused kernel that
- * keeps every weight gradient resident in MFMA accumulators.  Default 384 (-1 restores it), 0 = always fused. */
+ * keeps every weight gradient resident in MFMA accumulators.  Default 384 (-1 restores it), 0 = always fused.  While the
+ * split-fp32 training pass is on (ppo_set_bwd_split_bf16, the default) its fused backward is faster at every size and the
+ * threshold that applies is PPO_BWD_SMALL_MAX_TILES_SPLIT (default 0). */
 int32_t ppo_set_bwd_small_max_tiles(int64_t tiles);
 /* fp32 policies, fused backward (Policy(72, h, 2, 4)): 1 = its three big products (dH1 = dZ2 W2, dW2 += dZ2^T H1,
  * dW1 += dZ1^T X) run on the bf16 matrix pipe as SPLIT-fp32 products -- every fp32 operand is the exact sum of three

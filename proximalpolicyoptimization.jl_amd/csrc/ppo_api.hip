@@ -990,7 +990,13 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
     // the fused kernel is the num_hidden_layers == 2 shape with all its weight gradients resident (and F = 216 at HID = 256
     // does not fit its LDS): every other policy takes the layer-looped three-product form at any minibatch size
     const bool fused_ok = pol->L == 2 && !(pol->F == 216 && pol->HID == 256);
-    if ((B * (ro->H / 32) <= g_bwd_small_max_tiles || !fused_ok) && pol->dtype == PPO_DTYPE_F32) {
+    // with the split-fp32 fused backward (ppo_policy_bwd_x6.hip) the three-product form no longer wins at any size (measured,
+    // gpurun_out/small1: 128 / 256 / 384 tiles 30.3 / 35.6 / 49.4 ms per iteration against 28.4 / 35.5 / 43.8): it is taken only
+    // below PPO_BWD_SMALL_MAX_TILES_SPLIT (default 0) while the split form is on and covers the policy
+    static const int64_t small_max_split = [] { const char* v = std::getenv("PPO_BWD_SMALL_MAX_TILES_SPLIT"); return v ? (int64_t)atoll(v) : (int64_t)0; }();
+    const bool split_covers = ppo_bwd_split_enabled() && fused_ok && pol->F == 72 && pol->w2x.p != nullptr;
+    const int64_t small_max = split_covers ? small_max_split : g_bwd_small_max_tiles;
+    if ((B * (ro->H / 32) <= small_max || !fused_ok) && pol->dtype == PPO_DTYPE_F32) {
         const size_t frag = (size_t)pol->cap_tiles * (pol->HID / 32) * 1024;     // dZ in fragment order, like act1 / act2
         PPO_TRY(pol->dz1f.alloc(frag));
         if (pol->L >= 2) PPO_TRY(pol->dz2f.alloc(frag));

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 def P(ppo):
     if ppo.device_count() < 1:
         pytest.fail("no HIP device: the gpu-marked tests must run on the GPU box")
-    return ppo
+    yield ppo
+    ppo.set_bwd_split_bf16(None)          # (a test that switches the training-pass arithmetic and fails leaves the default behind)
 
 
 # ---------------------------------------------------------------- K6 returns / GAE
@@ -586,11 +587,14 @@ def test_gradient_with_reference_trained_weights(P, orc, golden_dir, fixture, bw
     assert np.array_equal(ro.selected_actions - 1, ref["actions"]) and np.array_equal(ro.selected_action_probabilities, ref["p_sel"])
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["fp32-mfma", "split-fp32"])
 @pytest.mark.parametrize("B", [256, 257, 384, 385, 512, 513])
-def test_gradient_at_the_kernel_switch_points(P, orc, B):
-    """Default kernel selection by minibatch size: 4 waves per state up to 256 states, 2 up to 512, one above; the
-    three-product backward up to 384 tiles, the fused kernel above.  Every size around the switch points gives the float64
-    oracle's gradient (same tolerance), through ppo_train's own path (device index list) as well."""
+def test_gradient_at_the_kernel_switch_points(P, orc, B, split):
+    """Default kernel selection by minibatch size.  fp32-MFMA training pass (ppo_set_bwd_split_bf16(0)): 4 waves per state up
+    to 256 states, 2 up to 512, one above; the three-product backward up to 384 tiles, the fused kernel above.  Split-fp32
+    pass (the default): one workgroup per state and the fused backward at every size.  Every size around the switch points
+    gives the float64 oracle's gradient (same tolerance)."""
+    P.set_bwd_split_bf16(split)
     env, pol, ro, ds = _make_dataset(P, orc, 48, 12, 256, seed=91)
     assert len(ds) == 576
     sel = np.random.default_rng(B).permutation(len(ds))[:B] + 1
@@ -600,7 +604,9 @@ def test_gradient_at_the_kernel_switch_points(P, orc, B):
     assert np.abs(g - g64).max() <= 2e-5 * np.abs(g64).max() + 1e-9
     assert abs(lp - olp) <= 1e-5 * (1 + abs(olp)) and abs(le - ole) <= 1e-5 * (1 + abs(ole))
     P.forward_backward(pol, ds, sel, 0.05, 0.01)
-    assert np.array_equal(g, pol.grad()), "bitwise reproducible run to run"
+    same = np.array_equal(g, pol.grad())
+    P.set_bwd_split_bf16(None)
+    assert same, "bitwise reproducible run to run"
 
 
 def test_gradient_clipped_branch(P, orc):
