@@ -59,6 +59,11 @@ end
 set_dtype!(p::HipPolicy, dtype::Symbol) =
     check(ccall((:ppo_policy_set_dtype, LIB), Int32, (Ptr{Cvoid}, Int32), p.h, dtype === :bf16 ? 1 : 0))
 
+# arithmetic of the fp32 TRAINING pass of Policy(72, h, 2, 4): true (default) = its Dense products as split-fp32 products on the
+# bf16 matrix pipe (three exact bfloat16 pieces per operand, six piece products, fp32 accumulation: the distance to a Float64
+# gradient is that of the fp32 kernels), false = fp32 MFMA.  Rollouts are not affected (their actions are pinned bit for bit).
+set_training_split_bf16!(on::Bool) = check(ccall((:ppo_set_bwd_split_bf16, LIB), Int32, (Int32,), on ? 1 : 0))
+
 # Flux.params(policy) round trip: flat vector in Flux order (W1,b1, the num_hidden_layers-1 hidden (W,b) pairs, W_out,b_out),
 # W [out,in] column-major; any num_hidden_layers in 1..4 (test/policy.jl:9-19)
 set_params!(p::HipPolicy, flat::Vector{Float32}) =
