@@ -727,7 +727,8 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6s(FwdArgs a, 
 #ifndef PPO_FWD_X6_T2_DEFAULT_MIN_TILES
 #define PPO_FWD_X6_T2_DEFAULT_MIN_TILES 1536
 #endif
-static int64_t g_fwd_x6_t2_min_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_T2_DEFAULT_MIN_TILES; }();
+// (read at every launch: the tests move the switch point to sizes their float64 checker finishes in seconds)
+static int64_t fwd_x6_t2_min_tiles() { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_T2_DEFAULT_MIN_TILES; }
 static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_DEFAULT_MAX_TILES; }();
 
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
@@ -765,7 +766,7 @@ int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int t
         hipLaunchKernelGGL((k_policy_fwd_train_x6s<256, 4>), dim3(nwg), dim3(512), lds, ppo_stream(), a,
                            (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);
     }
-    else if (p->HID == 256 && g_fwd_x6_t2_min_tiles > 0 && B >= g_fwd_x6_t2_min_tiles) {
+    else if (p->HID == 256 && fwd_x6_t2_min_tiles() > 0 && B >= fwd_x6_t2_min_tiles()) {
         constexpr int T = 2;
         const int64_t groups = (B + T - 1) / T;
         const int nwg = (int)(groups < 256 ? groups : 256);

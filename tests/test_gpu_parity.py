@@ -543,6 +543,8 @@ def _oracle_grad(orc, pol_params, HID, ro, sel0, eps, ew):
 
 @pytest.mark.parametrize("HID,B", [(128, 24), (128, 300), (256, 40), (256, 520)])
 def test_gradient_vs_f64_oracle(P, orc, HID, B, storage_mode, bwd_form):
+    if bwd_form == -2 and storage_mode:
+        pytest.skip("the fp32-MFMA form of the large-minibatch kernels: expanded storage only (suite time)")
     N, T = 40, 16
     env, pol, ro, ds = _make_dataset(P, orc, N, T, HID, seed=B)
     rng = np.random.default_rng(B)
@@ -594,6 +596,8 @@ def test_gradient_at_the_kernel_switch_points(P, orc, B, split):
     to 256 states, 2 up to 512, one above; the three-product backward up to 384 tiles, the fused kernel above.  Split-fp32
     pass (the default): one workgroup per state and the fused backward at every size.  Every size around the switch points
     gives the float64 oracle's gradient (same tolerance)."""
+    if split and B in (257, 384, 512):
+        pytest.skip("the split pass has no switch points of its own: three of the six sizes (suite time)")
     P.set_bwd_split_bf16(split)
     env, pol, ro, ds = _make_dataset(P, orc, 48, 12, 256, seed=91)
     assert len(ds) == 576

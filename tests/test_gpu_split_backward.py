@@ -22,6 +22,7 @@ def P(ppo):
     ppo.set_train_tile_max_tiles(None)
     ppo.set_bwd_split_bf16(None)
     ppo.set_rollout_compact(None)
+    os.environ.pop("PPO_FWD_SPLIT_T2_MIN_TILES", None)
 
 
 def _dataset(P, N, T, HID, seed):
@@ -57,14 +58,17 @@ def _oracle_grad(orc, params, HID, ro, sel0, eps, ew):
                                    ro.rewards.reshape(-1)[sel0], eps, ew)
 
 
-@pytest.mark.parametrize("HID,B,compact", [(256, 1537, True), (256, 900, False), (256, 333, True), (128, 1100, False), (128, 70, True)])
+@pytest.mark.parametrize("HID,B,compact", [(256, 401, True), (256, 600, False), (256, 333, True), (128, 1100, False), (128, 70, True)])
 def test_split_backward_matches_fp32_kernel_and_f64(P, orc, HID, B, compact):
     """Same minibatch through both kernels: each within 2e-5 max|g| of the float64 gradient (the bar of every gradient
     test), the split form no further from float64 than a small multiple of the fp32 chain's own distance, the two within
     fp32 rounding of each other, and the split form bitwise reproducible.  More tiles than workgroups (HID = 256: 1701 on
-    256) and fewer (70 on 512) both occur; from 1536 tiles on the HID = 256 train forward takes two tiles per workgroup pass
-    (1537: an odd count, the last pass has one tile), below it one."""
+    256) and fewer (70 on 512) both occur; from 1536 tiles on the HID = 256 train forward takes two tiles per workgroup pass,
+    below it one: the B = 401 case moves that switch to 200 tiles (PPO_FWD_SPLIT_T2_MIN_TILES, read per launch) -- an odd count,
+    the last pass has one tile."""
     P.set_rollout_compact(compact)
+    if B == 401:
+        os.environ["PPO_FWD_SPLIT_T2_MIN_TILES"] = "200"
     env, pol, ro, ds = _dataset(P, 48, 40 if B > 1152 else 24, HID, seed=B)
     pool = np.flatnonzero(_off_the_kink(pol.params, HID, ro.state_data[0].reshape(-1, 32, 72)))
     assert len(pool) >= 64                                           # (a minibatch may repeat samples)
