@@ -71,6 +71,13 @@ struct XCfg {
 
 // W2 piece fragments in flight ahead of the dH1 chain (3 per k-step).  HID = 256 runs at the 256-register budget: with
 // the chain's two accumulators a ring of 6 spills one accumulator tile inside the chain loop, 3 fits
+#ifndef PPO_X6_DMA_SPREAD
+// next-tile LDS-DMA loads spread through phase C's MFMA loop (bit 0: layer 2, bit 1: layer 1) or issued together in front of
+// it (0).  The spread form is OFF: on one of five boxes it made the HID = 128 kernel's dW3 differ between otherwise identical
+// launches (tools/x6_repro_check2.py: 23 of 30 trials there, 0 of 60 with the loads issued together on the same box; a build
+// that zeroes its LDS first shows none either) and the cause is not found -- see DESIGN.md section 3d.
+#define PPO_X6_DMA_SPREAD 0
+#endif
 #ifndef PPO_X6_RING
 #define PPO_X6_RING 6
 #endif
@@ -158,6 +165,16 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                          : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
         }
     };
+    // one of the four 1 KiB pieces of such a load (phase C issues them one per fragment set, between the MFMAs: eight loads
+    // issued back to back hold the wave at the issue stage for ~1200 clocks)
+    auto dma_one = [&](const float4* base, int64_t t, unsigned dst_lds, int q, unsigned ln) {
+        unsigned keep;
+        const float4* gsrc = base + ((size_t)t * NT + w) * 4 * 64 + ln + q * 64;
+        const unsigned dst = dst_lds + (unsigned)q * 1024u;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    };
+    (void)dma_one;
     float4 dy;
     uint2 xd[XPD];
     auto issue_tile_loads = [&](int64_t t, int sidx, unsigned ln) {
@@ -429,8 +446,12 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
             }
             // the next tile's inputs: fragments by LDS-DMA into the (now idle) regions, dY and the state dwords into registers
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of its H2^T rows have returned
+#if !(PPO_X6_DMA_SPREAD & 1)
             dma_frag(a.act2, ntile, h2slice_lds, ln);
+#endif
+#if !(PPO_X6_DMA_SPREAD & 2)
             dma_frag(a.act1, ntile, z2own_lds, ln);
+#endif
             {
                 int nidx = 0;
                 if (!a.x_by_tile) {
@@ -478,6 +499,13 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 accW2[kt] = x_mfma(ah[s], bc[1], accW2[kt]);
                 accW2[kt] = x_mfma(ah[s], bc[0], accW2[kt]);
                 __builtin_amdgcn_sched_barrier(0);
+#if PPO_X6_DMA_SPREAD
+                // the next tile's saved activations, one 1 KiB piece per fragment set (this wave's regions are idle since the
+                // lgkmcnt(0) above): layer 2 into the H2^T rows, layer 1 into the dZ2 fragment images
+                if ((PPO_X6_DMA_SPREAD & 1) && g < 4) dma_one(a.act2, ntile, h2slice_lds, g, ln);
+                else if ((PPO_X6_DMA_SPREAD & 2) && g >= 4 && g < 8) dma_one(a.act1, ntile, z2own_lds, g - 4, ln);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bc[p] = bn[p];
             }
