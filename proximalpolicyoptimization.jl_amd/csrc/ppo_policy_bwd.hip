@@ -225,6 +225,10 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
     };
     if ((int64_t)blockIdx.x < a.B)
         issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]));
+    // LDS-DMA data is ordered for a later ds_read only by the issuing wave's vmcnt wait FOLLOWED BY A BARRIER (see
+    // ppo_policy_bwd_x6.hip): the wait sits in front of the barrier that ends a tile (and this one, for the first tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #ifdef PPO_BWD_STAMP
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #define STAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
@@ -551,6 +555,7 @@ __global__ __launch_bounds__(HID * 2, (BwdCfg<F, HID>::MIN_WAVES)) void k_policy
         STAMP(9);
         if (!grads_first) tail_grads();
         STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the next tile's LDS-DMA has landed before the barrier its reads sit behind
         __syncthreads();
         STAMP(5);
     }

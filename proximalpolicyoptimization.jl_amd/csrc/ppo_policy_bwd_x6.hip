@@ -73,9 +73,8 @@ struct XCfg {
 // the chain's two accumulators a ring of 6 spills one accumulator tile inside the chain loop, 3 fits
 #ifndef PPO_X6_DMA_SPREAD
 // next-tile LDS-DMA loads spread through phase C's MFMA loop (bit 0: layer 2, bit 1: layer 1) or issued together in front of
-// it (0).  The spread form is OFF: on one of five boxes it made the HID = 128 kernel's dW3 differ between otherwise identical
-// launches (tools/x6_repro_check2.py: 23 of 30 trials there, 0 of 60 with the loads issued together on the same box; a build
-// that zeroes its LDS first shows none either) and the cause is not found -- see DESIGN.md section 3d.
+// it (0).  Off: the loads have to land before the barrier that ends the tile (see the loop), and the pieces issued last
+// would make that barrier wait for them.
 #define PPO_X6_DMA_SPREAD 0
 #endif
 #ifndef PPO_X6_RING
@@ -192,6 +191,12 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
         dma_frag(a.act1, blockIdx.x, z2own_lds, (unsigned)lane);
         issue_tile_loads(blockIdx.x, a.x_by_tile ? 0 : __builtin_amdgcn_readfirstlane(a.idx[blockIdx.x / a.tps]), (unsigned)lane);
     }
+    // LDS-DMA data is ordered for a later ds_read only by the issuing wave's vmcnt wait FOLLOWED BY A BARRIER (cdna_hip_programming.md,
+    // "read a staged buffer one phase after the wait that retires it"): a read right behind the wait can still see the old LDS
+    // content for part of the wave.  So the wait sits in front of the barrier that ends a tile (and this one, for the first tile),
+    // the reads of the landing zones behind it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
 #ifdef PPO_X6_STAMP
     unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
@@ -201,7 +206,6 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
 #endif
     for (int64_t tile = blockIdx.x; tile < a.B; tile += gridDim.x) {
         // ================= phase A: stage the tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // everything this wave has in flight (the DMAs included)
         {   // H1 (lane = row j, register 4q+e <-> feature e + 8q + 4h of tile w) -> three bf16 pieces -> images
             X6_LANE();
             // this lane's 8-byte chunks in the H1 piece images of feature tile w: row j, chunk (2q + h) ^ ((j >> 2) & 7)
@@ -511,7 +515,8 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
             }
         }
         XSTAMP(10);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's LDS-DMA (and register prefetch) of the next tile has landed ...
+        __syncthreads();                                            // ... and only behind this barrier are its landing zones read
         XSTAMP(11);
     }
 #ifdef PPO_X6_STAMP
