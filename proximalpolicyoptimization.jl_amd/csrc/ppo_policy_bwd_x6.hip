@@ -152,7 +152,8 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
     const unsigned h2slice_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)h2slice);
     const unsigned z2own_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)z2own);
     // LDS-DMA of a tile's fragments (4 x 1 KiB, lane-linear) into a region that only this wave touches; issued from inline
-    // asm and waited for with an explicit vmcnt(0) in phase A (see ppo_policy_bwd.hip for why hipcc must not know)
+    // asm (see ppo_policy_bwd.hip for why hipcc must not know) and waited for with an explicit vmcnt(0) in front of the barrier that
+    // ends the tile
     auto dma_frag = [&](const float4* base, int64_t t, unsigned dst_lds, unsigned ln) {
         const float4* src = base + ((size_t)t * NT + w) * 4 * 64 + ln;
 #pragma unroll
