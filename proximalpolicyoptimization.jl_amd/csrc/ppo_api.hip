@@ -960,7 +960,8 @@ static int32_t train_reserve(ppo_policy_s* p, int64_t B, bool compact = false) {
 
 // idx_dev: transition ids (already resolved through the dataset index)
 static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B,
-                                    int64_t B_global, double eps, double ew, int32_t adv_mode) {
+                                    int64_t B_global, double eps, double ew, int32_t adv_mode, ppo_adam_s* fuse_opt = nullptr,
+                                    float* fuse_hist2 = nullptr) {
     PPO_TRY(train_reserve(pol, B * (ro->H / 32), ro->compact));
     const float* adv = ro->returns.p;                       // batch_advantage = returns (reference-equivalent)
     if (adv_mode == PPO_ADV_GAE || adv_mode == PPO_ADV_GAE_NORMALISED) {
@@ -979,7 +980,7 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
         const int32_t ts = launch_policy_train_tile(pol, ro, idx_dev, B, B_global, eps, ew, adv);
         if (ts != PPO_ERR_UNSUPPORTED) {
             if (ts != PPO_OK) return ts;
-            PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
+            PPO_TRY(launch_grad_reduce(pol, B, B_global, ew, fuse_opt, fuse_hist2));
             pol->last_B = B; pol->last_entropy_weight = ew;
             return PPO_OK;
         }
@@ -1006,7 +1007,7 @@ static int32_t forward_backward_dev(ppo_policy_s* pol, ppo_rollouts_s* ro, const
     }
     if (bs != PPO_OK && bs != PPO_ERR_UNSUPPORTED) return bs;
     if (bs == PPO_ERR_UNSUPPORTED) PPO_TRY(launch_policy_bwd(pol, ro, idx_dev, B));
-    PPO_TRY(launch_grad_reduce(pol, B, B_global, ew));
+    PPO_TRY(launch_grad_reduce(pol, B, B_global, ew, fuse_opt, fuse_hist2));
     pol->last_B = B; pol->last_entropy_weight = ew;
     return PPO_OK;
 }
@@ -1138,14 +1139,17 @@ int32_t ppo_train(ppo_policy_t pol, ppo_adam_t opt, ppo_rollouts_t ro, double ep
             const int64_t B = std::max<int64_t>(0, std::min(batch_size, len - start));
             int64_t Bg = 0;
             for (int64_t l : lens) Bg += std::max<int64_t>(0, std::min(batch_size, l - start));
-            if (B > 0) PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, Bg, epsilon, entropy_weight, adv_mode));
+            // single-rank training: Adam and the re-pack ride in the slab-reduction launch (PPO_FUSE_REDUCE_ADAM=0: separate launches)
+            static const bool fuse_ok = [] { const char* v = std::getenv("PPO_FUSE_REDUCE_ADAM"); return v ? atoi(v) != 0 : true; }();
+            const bool fused = fuse_ok && !allreduce && B > 0;
+            if (B > 0) PPO_TRY(forward_backward_dev(pol, ro, order.p + start, B, Bg, epsilon, entropy_weight, adv_mode, fused ? opt : nullptr, hist.p + 2 * b));
             else HIP_TRY(hipMemsetAsync(pol->grad.p, 0, (size_t)(pol->np + 2) * sizeof(float), g_stream));   // shard exhausted
             if (allreduce) {                     // every rank of a data-parallel run; a world of 1 may pass it too
                 ProfScope ps("allreduce");
                 const int32_t s = allreduce(allreduce_ctx, pol->grad.p, pol->np + 2);
                 if (s != 0) { ppo_set_error("all-reduce hook failed"); return PPO_ERR_ARG; }
             }
-            PPO_TRY(launch_adam(opt, hist.p + 2 * b));                              // Flux.update!  :81 (+ loss history)
+            if (!fused) PPO_TRY(launch_adam(opt, hist.p + 2 * b));                  // Flux.update!  :81 (+ loss history)
         }
         opt->epochs_done += 1;
         PPO_TRY(d2h(hh.data(), hist.p, (size_t)nb * 2));

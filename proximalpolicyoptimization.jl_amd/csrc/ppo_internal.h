@@ -254,7 +254,8 @@ int32_t launch_policy_fwd_bf16(ppo_policy_s* p, FwdArgs& args, int mode, int64_t
 int32_t launch_policy_rollout_persistent_bf16(ppo_policy_s* p, FwdArgs& args, int64_t N, int tps, int V);
 int32_t launch_policy_bwd_bf16(ppo_policy_s* p, ppo_rollouts_s* ro, const int32_t* idx_dev, int64_t B);
 static inline int bf16_ks1(int F) { return (F + 15) / 16; }     // layer-1 k-steps of 16 (zero padded)
-int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight);
+// fuse (optional): apply Adam + re-pack in the same launch (single-rank training); hist2: the per-batch loss pair of that step
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight, ppo_adam_s* fuse = nullptr, float* hist2 = nullptr);
 int32_t launch_adam(ppo_adam_s* o, float* hist2_or_null);
 int32_t launch_categorical(const float* probs, const float* u, int64_t B, int64_t A, int32_t* actions, float* psel,
                            int32_t* err);

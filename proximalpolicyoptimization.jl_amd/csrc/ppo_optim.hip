@@ -25,15 +25,30 @@ static ParamLayout layout_of(const ppo_policy_s* p) {
 __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, double inv_Bg, double entropy_weight,
                                   float* __restrict__ grad_tail);
 
+struct PackPtrs {
+    float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3;
+    // bf16 compute mode (null in fp32 mode): A-operand fragments of v_mfma_f32_32x32x16_bf16 (ppo_policy_bf16.hip)
+    uint16_t* w1b; uint16_t* w2b; uint16_t* w2tb; uint16_t* w3c; uint16_t* w3tb;
+    // split-fp32 backward (null when the policy has none): W2 as three bf16 pieces (ppo_policy_bwd_x6.hip)
+    uint16_t* w2x; uint16_t* w1x; uint16_t* w2fx;
+};
+
+// Adam fused into the slab reduction (single-rank training: no all-reduce between them): the thread that holds an element's
+// gradient sum applies Flux's legacy Adam to that parameter and re-packs it -- one launch and one pass over the gradient less
+struct AdamFuse { float* params; float* m; float* v; double eta, beta1, beta2, eps, bp1, bp2; float* hist2; int on; };
+__device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P, int64_t i, float x);
+__device__ __forceinline__ void adam_one(const AdamFuse& A, const ParamLayout& L, const PackPtrs& P, int64_t i, float g);
+
 // Block = 64 consecutive slab elements x 4 slab groups (wave g sums slabs g, g+4, g+8, ... with 8 loads in flight);
 // the four partial sums meet in LDS and are added in a fixed order.  4x the waves of a one-thread-per-element
 // layout: the 87 MB slab walk needs the memory-level parallelism (341 blocks of one wave per SIMD did 3.3 TB/s).
 // nwg_w slabs carry weight-gradient partials, nwg_s slabs the small-gradient tails (equal for the fused backward)
 __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ slabs, size_t slab_stride, int nwg_w, int nwg_s, ParamLayout L,
                                                      float* __restrict__ grad, const double* __restrict__ terms, int64_t B,
-                                                     double inv_Bg, double entropy_weight) {
+                                                     double inv_Bg, double entropy_weight, AdamFuse A, PackPtrs P) {
     if (blockIdx.x == gridDim.x - 1) {          // the extra last block reduces the per-sample loss terms
         loss_reduce_block(terms, B, inv_Bg, entropy_weight, grad + L.np);
+        if (A.on && A.hist2 && threadIdx.x == 0) { A.hist2[0] = grad[L.np]; A.hist2[1] = grad[L.np + 1]; }   // per-batch loss history (k_adam's job otherwise)
         return;
     }
     __shared__ float part[4][64];
@@ -86,7 +101,10 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const float* __restrict__ s
         else if ((e2 -= (size_t)L.HID * L.NL2) < (size_t)L.HID * 4) canon = L.offW3 + (int64_t)(e2 & 3) + 4 * (int64_t)(e2 >> 2);
         else canon = L.offb3 + (int64_t)(e2 - (size_t)L.HID * 4);
     }
-    if (canon >= 0) grad[canon] = s;
+    if (canon >= 0) {
+        grad[canon] = s;
+        if (A.on) adam_one(A, L, P, canon, s);
+    }
 }
 
 // loss scalars: grad[np] = -(sum min)/B_global, grad[np+1] = entropy_weight * -(sum H)/B_global.
@@ -117,13 +135,6 @@ __device__ void loss_reduce_block(const double* __restrict__ terms, int64_t B, d
 }
 
 // ---------------------------------------------------------------- Adam + pack
-struct PackPtrs {
-    float* w1p; float* w2p; float* w2tp; float* b1p; float* b2p; float* w3p; float* b3;
-    // bf16 compute mode (null in fp32 mode): A-operand fragments of v_mfma_f32_32x32x16_bf16 (ppo_policy_bf16.hip)
-    uint16_t* w1b; uint16_t* w2b; uint16_t* w2tb; uint16_t* w3c; uint16_t* w3tb;
-    // split-fp32 backward (null when the policy has none): W2 as three bf16 pieces (ppo_policy_bwd_x6.hip)
-    uint16_t* w2x; uint16_t* w1x; uint16_t* w2fx;
-};
 
 __device__ __forceinline__ uint16_t to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }   // RNE
 // x = h + m + l: each piece the RNE bf16 of what the previous ones left (the differences are exact in fp32)
@@ -225,6 +236,18 @@ __device__ __forceinline__ void pack_one(const ParamLayout& L, const PackPtrs& P
     }
 }
 
+// Flux legacy Adam on one parameter (the arithmetic of k_adam), then its packed copies
+__device__ __forceinline__ void adam_one(const AdamFuse& A, const ParamLayout& L, const PackPtrs& P, int64_t i, float g) {
+    const double gd = (double)g;
+    const float mn = (float)(A.beta1 * (double)A.m[i] + (1.0 - A.beta1) * gd);
+    const float vn = (float)(A.beta2 * (double)A.v[i] + ((1.0 - A.beta2) * gd) * gd);
+    A.m[i] = mn; A.v[i] = vn;
+    const double delta = (double)mn / (1.0 - A.bp1) / (sqrt((double)vn / (1.0 - A.bp2)) + A.eps) * A.eta;
+    const float x = A.params[i] - (float)delta;
+    A.params[i] = x;
+    pack_one(L, P, i, x);
+}
+
 __global__ void k_pack_params(const float* __restrict__ params, ParamLayout L, PackPtrs P) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.np) return;
@@ -277,14 +300,20 @@ int32_t launch_pack_params(ppo_policy_s* p) {
 }
 
 // slab reduction + (one extra block) loss-term reduction in a single launch
-int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight) {
+int32_t launch_grad_reduce(ppo_policy_s* p, int64_t B, int64_t B_global, double entropy_weight, ppo_adam_s* fuse, float* hist2) {
     ParamLayout L = layout_of(p);
     const size_t total = (size_t)L.NL2 * L.HID * L.HID + (size_t)L.HID * L.FP + (size_t)L.HID * (1 + L.NL2) + (size_t)L.HID * 4 + 4;
-    ProfScope ps("k_grad_reduce");
+    AdamFuse A = {};
+    if (fuse) {
+        A.params = p->params.p; A.m = fuse->m.p; A.v = fuse->v.p; A.eta = fuse->eta; A.beta1 = fuse->beta1; A.beta2 = fuse->beta2;
+        A.eps = fuse->eps; A.bp1 = fuse->beta_pow[0]; A.bp2 = fuse->beta_pow[1]; A.hist2 = hist2; A.on = 1;
+    }
+    ProfScope ps(fuse ? "k_reduce_adam" : "k_grad_reduce");
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((total + 63) / 64) + 1), dim3(256), 0, ppo_stream(), p->slabs.p,
                        slab_floats(p->F, p->HID, p->L), p->nwg_bwd, p->nwg_small ? p->nwg_small : p->nwg_bwd, L, p->grad.p, p->loss_terms.p, B, 1.0 / (double)B_global,
-                       entropy_weight);
+                       entropy_weight, A, packs_of(p));
     HIP_TRY(hipGetLastError());
+    if (fuse) { fuse->beta_pow[0] *= fuse->beta1; fuse->beta_pow[1] *= fuse->beta2; }
     return PPO_OK;
 }
 

@@ -22,7 +22,9 @@ def _iteration(P, seed, out, key):
             P.collect_rollouts_steps_(ro, env, pol, 16, 0.99)
             ds = P.construct_dataset(ro)
             P.ppo_train_(pol, opt, ds, 0.05, 256, 2, 0.01, seed=100 + it, verbose=False)
-        ms, n = P.profile_get("k_adam")
+        ms, n = P.profile_get("k_reduce_adam")                 # single-rank training: Adam rides in the slab-reduction launch
+        if n == 0:
+            ms, n = P.profile_get("k_adam")
         P.profile_enable(False)
         out[key] = (pol.params.copy(), ro.selected_actions.copy(), ro.rewards.copy(), n)
     except Exception as e:                                    # surfaced by the asserting thread
