@@ -17,4 +17,4 @@ for v in 0 1; do
     PPO_BWD_SPLIT_BF16=$v PPO_BENCH_FORCE_DIST=1 timeout -k 10 200 $B --envs $e > $O/shard_${e}_$v.json 2> $O/shard_${e}_$v.err && python3 tools/show_bench.py $O/shard_${e}_$v.json envs=$e split=$v
   done
 done
-[ -f proximalpolicyoptimization.jl_amd/libppo_hip_xstamp.so ] && timeout -k 10 120 python3 tools/x6_stamps.py 256 > $O/stamps256.txt 2>&1 && cat $O/stamps256.txt
+if [ -f proximalpolicyoptimization.jl_amd/libppo_hip_xstamp.so ]; then timeout -k 10 120 python3 tools/x6_stamps.py 256 > $O/stamps256.txt 2>&1 && cat $O/stamps256.txt; fi
