@@ -729,6 +729,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6s(FwdArgs a, 
 #endif
 // (read at every launch: the tests move the switch point to sizes their float64 checker finishes in seconds)
 static int64_t fwd_x6_t2_min_tiles() { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_T2_DEFAULT_MIN_TILES; }
+// the same switch for HID = 128 (PPO_FWD_SPLIT_T2_MIN_TILES_128; 0 = never).  Measured (gpurun_out/h128_t2, alternating): train forward
+// 0.0570 -> 0.0548 ms at 4096 states, 6.00 -> 6.09 M env-steps/s
+static int64_t fwd_x6_t2_min_tiles_128() { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES_128"); return v ? (int64_t)atoll(v) : (int64_t)1024; }
 static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_DEFAULT_MAX_TILES; }();
 
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
@@ -777,6 +780,19 @@ int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int t
             attr_set2 = true;
         }
         hipLaunchKernelGGL((k_policy_fwd_train_x6t<256, T>), dim3(nwg), dim3(512), lds, ppo_stream(), a,
+                           (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);
+    }
+    else if (p->HID == 128 && fwd_x6_t2_min_tiles_128() > 0 && B >= fwd_x6_t2_min_tiles_128()) {
+        constexpr int T = 2;                                       // 54 KB of LDS per workgroup: two (four-wave) workgroups per CU
+        const int64_t groups = (B + T - 1) / T;
+        const int nwg = (int)(groups < 512 ? groups : 512);
+        const size_t lds = FXTCfg<128, T>::total;
+        static thread_local bool attr_set3 = false;
+        if (!attr_set3) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_policy_fwd_train_x6t<128, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set3 = true;
+        }
+        hipLaunchKernelGGL((k_policy_fwd_train_x6t<128, T>), dim3(nwg), dim3(256), lds, ppo_stream(), a,
                            (const uint4*)p->w1x.p, (const uint4*)p->w2fx.p, compact ? 1 : 0);
     }
     else if (p->HID == 256) LAUNCH(256);

@@ -23,6 +23,7 @@ def P(ppo):
     ppo.set_bwd_split_bf16(None)
     ppo.set_rollout_compact(None)
     os.environ.pop("PPO_FWD_SPLIT_T2_MIN_TILES", None)
+    os.environ.pop("PPO_FWD_SPLIT_T2_MIN_TILES_128", None)
 
 
 def _dataset(P, N, T, HID, seed):
@@ -69,6 +70,8 @@ def test_split_backward_matches_fp32_kernel_and_f64(P, orc, HID, B, compact):
     P.set_rollout_compact(compact)
     if B == 401:
         os.environ["PPO_FWD_SPLIT_T2_MIN_TILES"] = "200"
+    if (HID, B) == (128, 70):
+        os.environ["PPO_FWD_SPLIT_T2_MIN_TILES_128"] = "32"       # (HID = 128 switches at 1024 tiles; B = 1100 takes it by itself)
     env, pol, ro, ds = _dataset(P, 48, 40 if B > 1152 else 24, HID, seed=B)
     pool = np.flatnonzero(_off_the_kink(pol.params, HID, ro.state_data[0].reshape(-1, 32, 72)))
     assert len(pool) >= 64                                           # (a minibatch may repeat samples)
