@@ -11,6 +11,7 @@
 //   version 2: states = the env snapshots they are derived from, N*2V int8 (score[V] then degree[V]: 64 B for Q = 8) --
 //              the default while streaming (ppo_set_rollout_compact): 81 instead of 2321 bytes per env-step over PCIe
 #include "ppo_internal.h"
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -53,7 +54,8 @@ struct DiskSink {
     std::condition_variable cv;
     int64_t enq = 0, written = 0;         // records handed to the copy stream / written to the file
     int batch = 1;                        // records per writev()
-    bool stop = false, failed = false;
+    bool stop = false;
+    std::atomic<bool> failed{false};      // set by the writer thread outside the lock, read by the host thread
     // deferred finish (ppo_set_disk_async): the ring holds the whole collection, ppo_collect_rollouts returns as soon as the
     // last step is on the copy stream, and the writer thread appends the returns column and closes the file by itself
     bool async_fin = false;               // this collection finishes in the writer thread
@@ -356,7 +358,9 @@ int32_t disk_sink_finish(ppo_rollouts_s* ro) {
         HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ret_ready, 0));
         HIP_TRY(hipMemcpyAsync(s->ret_pinned, ro->returns.p, nb, hipMemcpyDeviceToHost, s->copy_stream));
         HIP_TRY(hipEventRecord(s->ret_copied, s->copy_stream));
-        { std::lock_guard<std::mutex> lk(s->mu); s->T_total = ro->T; s->fin_pending = true; }
+        // the finish is due once every record handed over so far is in the file (== ro->T steps unless a step failed to
+        // enqueue: the count the writer can actually reach, so a short collection can never leave it waiting)
+        { std::lock_guard<std::mutex> lk(s->mu); s->T_total = s->enq; s->fin_pending = true; }
         s->cv.notify_all();
         return PPO_OK;
     }
