@@ -447,10 +447,10 @@ int32_t ppo_policy_create(int32_t F, int32_t hidden_user, int32_t num_hidden_lay
         (s = p->b2p.alloc((size_t)(NL2 > 0 ? NL2 : 1) * hidden)) ||
         (s = p->w3p.alloc((size_t)hidden * PPO_OUT)) || (s = p->b3.alloc(PPO_OUT)) || (s = p->grad.alloc(p->np + 2)) ||
         (s = p->err.alloc(1))) { delete p; return s; }
-    if (num_hidden_layers == 2 && F == 72) {             // + 4 KiB: the operand ring of the last k-steps reads ahead
-        if ((s = p->w2x.alloc((size_t)3 * hidden * hidden + 4096))) { delete p; return s; }
+    if (num_hidden_layers == 2 && F == 72) {             // + 16 KiB: the operand ring of the last k-steps reads ahead (up to 12 KiB)
+        if ((s = p->w2x.alloc((size_t)3 * hidden * hidden + 8192))) { delete p; return s; }
         (void)hipMemsetAsync(p->w2x.p, 0, p->w2x.n * 2, g_stream);
-        if ((s = p->w2fx.alloc((size_t)3 * hidden * hidden + 4096)) || (s = p->w1x.alloc((size_t)(hidden / 32) * 5 * 3 * 512 + 4096))) { delete p; return s; }
+        if ((s = p->w2fx.alloc((size_t)3 * hidden * hidden + 8192)) || (s = p->w1x.alloc((size_t)(hidden / 32) * 5 * 3 * 512 + 4096))) { delete p; return s; }
         (void)hipMemsetAsync(p->w2fx.p, 0, p->w2fx.n * 2, g_stream);
         (void)hipMemsetAsync(p->w1x.p, 0, p->w1x.n * 2, g_stream);       // inputs 72 .. 79 of the last k-step stay zero
     }

@@ -80,8 +80,11 @@ struct XCfg {
 #ifndef PPO_X6_RING
 #define PPO_X6_RING 6
 #endif
+// W2 pieces in flight per wave in the dH1 chain.  The chain waits on the L2 (one k-step of prefetch distance is ~200-400 clocks
+// of MFMA work, an L2 hit is longer), so the ring is as deep as the registers allow: at HID = 256 that is 4 (256 VGPRs, no
+// scratch; 6 spills 72 B and measured slower, 3 -> 4: 0.2484 -> 0.2440 ms, gpurun_out/rd4, tools/r3_rd4_ab.sh)
 #ifndef PPO_X6_RING_256
-#define PPO_X6_RING_256 3
+#define PPO_X6_RING_256 4
 #endif
 
 template <int F, int HID>
@@ -341,36 +344,40 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accs[r] = 0.0f;
             const char* wn = wx + (size_t)RD * 1024;
-            static_assert(RD % 3 == 0 && KS % (RD / 3) == 0, "ring rounds");
+            // ring entry i of the stream (i = 3 k + piece) lives in slot i % RD; a round is the fewest k-steps after which the
+            // slots repeat (RD = 3: 1, RD = 6: 2, RD = 4: 4), so every slot index below is a compile-time constant
+            constexpr int RU = (RD % 3 == 0) ? RD / 3 : RD;
+            static_assert(KS % RU == 0 && (3 * RU) % RD == 0, "ring rounds");
             unsigned zo = (unsigned)lane * 16u;
             asm volatile("" : "+v"(zo));
             const char* zp = fragZ2 + zo;
             const unsigned lo16 = zo;
 #pragma unroll 1
-            for (int k0 = 0; k0 < KS; k0 += RD / 3) {
+            for (int k0 = 0; k0 < KS; k0 += RU) {
 #pragma unroll
-                for (int u = 0; u < RD / 3; ++u) {
+                for (int u = 0; u < RU; ++u) {
+                    const int s0 = (3 * u + 0) % RD, s1 = (3 * u + 1) % RD, s2 = (3 * u + 2) % RD;
                     const uint4 z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
                     const uint4 z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
                     const uint4 z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
-                    accs = x_mfma(z_h, ring[3 * u + 0], accs);
+                    accs = x_mfma(z_h, ring[s0], accs);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    ring[s0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
                     __builtin_amdgcn_sched_barrier(0);
-                    accs = x_mfma(z_m, ring[3 * u + 1], accs);
-                    accs = x_mfma(z_h, ring[3 * u + 1], accs);
+                    accs = x_mfma(z_m, ring[s1], accs);
+                    accs = x_mfma(z_h, ring[s1], accs);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    ring[s1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
                     __builtin_amdgcn_sched_barrier(0);
-                    accs = x_mfma(z_l, ring[3 * u + 2], accs);
-                    accs = x_mfma(z_m, ring[3 * u + 2], accs);
-                    acc = x_mfma(z_h, ring[3 * u + 2], acc);
+                    accs = x_mfma(z_l, ring[s2], accs);
+                    accs = x_mfma(z_m, ring[s2], accs);
+                    acc = x_mfma(z_h, ring[s2], acc);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    ring[s2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
                     wn += 3 * 1024;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                zp += (RD / 3) * 3 * 1024;
+                zp += RU * 3 * 1024;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = acc[r] + accs[r];
