@@ -77,6 +77,11 @@ struct XCfg {
 // would make that barrier wait for them.
 #define PPO_X6_DMA_SPREAD 0
 #endif
+// A/B knob (make -C csrc xprio): wave priority raised while a wave runs its MFMA loops (bit 0: the dH1 chain, bit 1: dW2), so that
+// the SIMD partner's vector phases (splits, small gradients) do not take issue slots from it.  Not measured yet: off.
+#ifndef PPO_X6_PRIO
+#define PPO_X6_PRIO 0
+#endif
 #ifndef PPO_X6_RING
 #define PPO_X6_RING 6
 #endif
@@ -329,6 +334,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
         if (grads_first) small_grads();
         XSTAMP(4);
         {
+#if PPO_X6_PRIO & 1
+            __builtin_amdgcn_s_setprio(2);
+#endif
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -381,6 +389,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = acc[r] + accs[r];
+#if PPO_X6_PRIO & 1
+            __builtin_amdgcn_s_setprio(0);
+#endif
             XSTAMP(5);
             // acc: dH1, lane = feature 32w + j, register r <-> tile row (r&3) + 8(r>>2) + 4h.  dZ1 = dH1 . lrelu'(H1): the sign
             // of H1 from the first piece of its image, read transposed (block rows 8g + 4h .. +3 = registers 4g .. 4g+3)
@@ -497,6 +508,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 b[2] = x_tr_frag(i0 + 2 * NT * 2048 + tb[s][0], i0 + 2 * NT * 2048 + tb[s][1]);
             };
             XSTAMP(9);
+#if PPO_X6_PRIO & 2
+            __builtin_amdgcn_s_setprio(2);
+#endif
             uint4 bc[3], bn[3];
             load_b(0, bc);
 #pragma unroll
@@ -522,6 +536,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 for (int p = 0; p < 3; ++p) bc[p] = bn[p];
             }
         }
+#if PPO_X6_PRIO & 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         XSTAMP(10);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's LDS-DMA (and register prefetch) of the next tile has landed ...
         __syncthreads();                                            // ... and only behind this barrier are its landing zones read
