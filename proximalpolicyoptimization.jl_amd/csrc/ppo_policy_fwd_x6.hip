@@ -273,6 +273,12 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
     float4* const sB2 = reinterpret_cast<float4*>(smem_c + C::oB2);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PPO_FX6_STAMP
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#define FXSTAMP(i) do { unsigned long long _n = clock64(); st_sum[i] += _n - st_t; st_t = _n; } while (0)
+#else
+#define FXSTAMP(i) do { } while (0)
+#endif
     for (int i = tid; i < 2 * NT * 16; i += NT * 64) sW3p[i] = a.w3p[i];
     for (int i = tid; i < NT * 8; i += NT * 64) { sB1[i] = a.b1p[i]; sB2[i] = a.b2p[i]; }
     __syncthreads();
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 if (st + R1 < 3 * K1) ring[st % R1] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)(st + R1) * 1024u));
                 __builtin_amdgcn_sched_barrier(0);
             }
+            FXSTAMP(0);
 #pragma unroll
             for (int i = 0; i < T; ++i) {
 #pragma unroll
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 }
             }
         }
+        FXSTAMP(1);
         constexpr int RD = 6;
         static_assert(KS % (RD / 3) == 0, "ring rounds");
         uint4 ring[RD];
@@ -388,7 +396,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 load_x(i, x_by_tile ? t : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[t]), ln2);
             }
         }
+        FXSTAMP(2);
         __syncthreads();                                                // (1) every layer-1 tile of the T states is in LDS
+        FXSTAMP(3);
         // ================= layer 2
         {
             X6F_LANE();
@@ -433,6 +443,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 }
                 zp += (RD / 3) * 3 * 1024;
             }
+            FXSTAMP(4);
 #pragma unroll
             for (int i = 0; i < T; ++i) {
 #pragma unroll
@@ -460,7 +471,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 sP[(i * NT + w) * 64 + ln] = make_float4(p0, p1, p2, p3);
             }
         }
+        FXSTAMP(5);
         __syncthreads();                                                // (2) partial logits in LDS; the H1 fragments are free
+        FXSTAMP(6);
         if (w < T && g * T + w < a.B) {                                 // wave i runs the loss tail of tile i
             X6F_LANE();
             const int64_t tile = g * T + w;
@@ -477,7 +490,13 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             l[0][3] = (s.w + __shfl_xor(s.w, 32)) + a.b3[3];
             policy_tail<2, 1, false>(a, tile, sidw, act, l, (int)ln, j, h);
         }
+        FXSTAMP(7);
     }
+#ifdef PPO_FX6_STAMP
+    if (a.stamps && lane == 0 && (w == 0 || w == NT - 1))
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + i] = st_sum[i];
+#endif
+#undef FXSTAMP
 }
 
 template <int HID, int TPS>
@@ -734,8 +753,22 @@ static int64_t fwd_x6_t2_min_tiles() { const char* v = std::getenv("PPO_FWD_SPLI
 static int64_t fwd_x6_t2_min_tiles_128() { const char* v = std::getenv("PPO_FWD_SPLIT_T2_MIN_TILES_128"); return v ? (int64_t)atoll(v) : (int64_t)1024; }
 static int64_t g_fwd_x6_max_tiles = [] { const char* v = std::getenv("PPO_FWD_SPLIT_MAX_TILES"); return v ? (int64_t)atoll(v) : (int64_t)PPO_FWD_X6_DEFAULT_MAX_TILES; }();
 
+#ifdef PPO_FX6_STAMP
+// diagnostic build (make -C csrc fxstamp, tools/fx6_stamps.py): per-phase clocks of k_policy_fwd_train_x6t, [workgroup][wave 0 / last][8]
+static unsigned long long* g_fx6_stamps = nullptr;
+extern "C" int32_t ppo_debug_fx6_stamps(unsigned long long* out) {
+    if (!g_fx6_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out, g_fx6_stamps, 512 * 2 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int32_t launch_policy_train_fwd_x6(ppo_policy_s* p, FwdArgs& a, int64_t B, int tps, bool compact) {
     if (!ppo_bwd_split_enabled() || B > g_fwd_x6_max_tiles) return PPO_ERR_UNSUPPORTED;
+#ifdef PPO_FX6_STAMP
+    if (!g_fx6_stamps) { (void)hipMalloc((void**)&g_fx6_stamps, 512 * 2 * 8 * 8); (void)hipMemset(g_fx6_stamps, 0, 512 * 2 * 8 * 8); }
+    a.stamps = g_fx6_stamps;
+#endif
     if (p->dtype != PPO_DTYPE_F32 || p->L != 2 || p->F != 72 || !(tps == 1 || (tps == 4 && p->HID == 256)) || !p->w1x.p || !p->w2fx.p) return PPO_ERR_UNSUPPORTED;
     if (compact) {
         // env snapshots: the minibatch's observation rows are re-derived first (the arithmetic of state(env), ppo_env.hip) into
