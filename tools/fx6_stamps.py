@@ -29,10 +29,10 @@ assert L.ppo_debug_fx6_stamps(out.ctypes.data) == 0
 s = out[: nwg * 16].reshape(nwg, 2, 8).astype(np.float64)
 passes = groups / nwg
 names = ["layer 1: X convert + 15 x 2 MFMAs", "H1 store, split, LDS fragments", "W2 ring fill + next X issue", "barrier 1",
-         "layer 2: 16 k-steps x 12 MFMAs", "H2 store + layer-3 partial dots", "barrier 2", "loss tail (waves 0, 1)"]
+         "layer 2: hid/16 k-steps x 12 MFMAs", "H2 store + layer-3 partial dots", "barrier 2", "loss tail (waves 0, 1)"]
 for wv in (0, 1):
     m = s[:, wv, :].mean(axis=0)
     print("wave %s: total %.0f cycles/WG (%.0f per two-tile pass; MFMA issue of the SIMD's two waves: %d)" %
-          ("0" if wv == 0 else "last", m.sum(), m.sum() / passes, 2 * 2 * (15 + 96) * 32))
+          ("0" if wv == 0 else "last", m.sum(), m.sum() / passes, 2 * 2 * (15 + hid // 16 * 6) * 32))
     for n, v in zip(names, m):
         print("   %-36s %8.0f per pass  %5.1f %%" % (n, v / passes, 100 * v / m.sum()))
