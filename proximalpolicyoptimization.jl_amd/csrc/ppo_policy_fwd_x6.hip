@@ -251,6 +251,13 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
 // through both layers against ONE pass over its weight stream: every W1 / W2 piece fragment feeds T MFMAs.  T x 48 KB of H1
 // fragments: one workgroup per CU, two waves per SIMD; the T independent accumulator chains per wave stand in for the second
 // workgroup's latency hiding.
+// A/B knob (make -C csrc fsidx): the two-tile train forward reads its transition ids (and the active word of the tail) through the
+// scalar cache instead of vector loads + readfirstlane, each of which waits for vmcnt(0) -- every store and load in flight.
+// Not measured yet: off.
+#ifndef PPO_FX6_SIDX
+#define PPO_FX6_SIDX 0
+#endif
+
 template <int HID, int T>
 struct FXTCfg {
     static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;
@@ -297,6 +304,23 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
     };
     // tile i of group g is g*T + i; a group that runs past the minibatch re-does the last tile and discards it
     auto tile_of = [&](int64_t g, int i) { const int64_t t = g * T + i; return t < a.B ? t : a.B - 1; };
+#if PPO_FX6_SIDX
+    // transition ids of a pass through the scalar cache, both in one wait (a vector load + readfirstlane waits on vmcnt(0), i.e.
+    // on every activation store and operand load the wave has in flight, twice per pass)
+    static_assert(T == 2, "two scalar loads per pass");
+    int cid[T] = {0, 0}, nid[T] = {0, 0};
+    auto sload_ids = [&](int64_t g, int (&id)[T]) {
+        const int32_t* const ip0 = a.idx + tile_of(g, 0);
+        const int32_t* const ip1 = a.idx + tile_of(g, 1);
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(id[0]), "=&s"(id[1]) : "s"(ip0), "s"(ip1) : "memory");
+    };
+    if ((int64_t)blockIdx.x * T < a.B) {
+        sload_ids(blockIdx.x, cid);
+#pragma unroll
+        for (int i = 0; i < T; ++i) load_x(i, x_by_tile ? tile_of(blockIdx.x, i) : (int64_t)cid[i], (unsigned)lane);
+    }
+#else
     if ((int64_t)blockIdx.x * T < a.B) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
@@ -304,6 +328,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             load_x(i, x_by_tile ? t : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[t]), (unsigned)lane);
         }
     }
+#endif
     for (int64_t g = blockIdx.x; g * T < a.B; g += gridDim.x) {
         // ================= layer 1: H1 tile w of the T states
         {
@@ -390,11 +415,17 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             const int64_t gn = ((g + gridDim.x) * T < a.B) ? g + gridDim.x : g;
             unsigned ln2 = (unsigned)lane;
             asm volatile("" : "+v"(ln2));
+#if PPO_FX6_SIDX
+            sload_ids(gn, nid);
+#pragma unroll
+            for (int i = 0; i < T; ++i) load_x(i, x_by_tile ? tile_of(gn, i) : (int64_t)nid[i], ln2);
+#else
 #pragma unroll
             for (int i = 0; i < T; ++i) {
                 const int64_t t = tile_of(gn, i);
                 load_x(i, x_by_tile ? t : (int64_t)__builtin_amdgcn_readfirstlane(a.idx[t]), ln2);
             }
+#endif
         }
         FXSTAMP(2);
         __syncthreads();                                                // (1) every layer-1 tile of the T states is in LDS
@@ -477,8 +508,17 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
         if (w < T && g * T + w < a.B) {                                 // wave i runs the loss tail of tile i
             X6F_LANE();
             const int64_t tile = g * T + w;
+#if PPO_FX6_SIDX
+            const int32_t sidw = w == 0 ? cid[0] : cid[1];
+            uint32_t act;
+            {
+                const uint32_t* const ap = a.active + sidw;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(act) : "s"(ap) : "memory");
+            }
+#else
             const int32_t sidw = __builtin_amdgcn_readfirstlane(a.idx[tile]);
             const uint32_t act = a.active[sidw];
+#endif
             const float4* sPi = sP + (size_t)w * NT * 64;
             float4 s = sPi[ln];
 #pragma unroll
@@ -491,6 +531,9 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             policy_tail<2, 1, false>(a, tile, sidw, act, l, (int)ln, j, h);
         }
         FXSTAMP(7);
+#if PPO_FX6_SIDX
+        cid[0] = nid[0]; cid[1] = nid[1];
+#endif
     }
 #ifdef PPO_FX6_STAMP
     if (a.stamps && lane == 0 && (w == 0 || w == NT - 1))

@@ -1,17 +1,18 @@
 #!/bin/bash
-# first A/B of round 4, prepared at the end of round 3 (no GPU minutes left then): wave priority in the MFMA loops of the split
-# backward.  Build first: make -C proximalpolicyoptimization.jl_amd/csrc xprio   (libppo_hip_xprio{1,2,3}.so travel with the snapshot)
+# first A/B of round 4, prepared at the end of round 3 (no GPU minutes left then): (1) wave priority in the MFMA loops of the split
+# backward (xprio1..3), (2) transition ids of the two-tile split train forward through the scalar cache instead of vector loads that wait
+# for vmcnt(0) (fsidx).  Build first: make -C proximalpolicyoptimization.jl_amd/csrc xprio fsidx   (the .so files travel with the snapshot)
 # usage (on the box): bash tools/r4_first_ab.sh [outdir]
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-xprio}; mkdir -p $O
 P=$GRAFT_REPO_ROOT/proximalpolicyoptimization.jl_amd
-for r in 1 2; do for v in default xprio1 xprio2 xprio3; do
+for r in 1 2; do for v in default fsidx xprio1 xprio2 xprio3; do
   L=""; [ $v != default ] && L=$P/libppo_hip_$v.so
   [ -z "$L" ] || [ -f "$L" ] || { echo "missing $L"; continue; }
   PPO_HIP_LIB=$L timeout -k 10 60 python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/b_${v}_$r.json 2> $O/b_${v}_$r.err && python3 tools/show_bench.py $O/b_${v}_$r.json $v | cut -c1-170
 done; done
-for v in xprio1 xprio2 xprio3; do
+for v in fsidx xprio1 xprio2 xprio3; do
   [ -f $P/libppo_hip_$v.so ] || continue
   PPO_HIP_LIB=$P/libppo_hip_$v.so timeout -k 10 90 python3 -m pytest tests/test_gpu_split_backward.py -x -q > $O/tests_$v.log 2>&1; echo tests_$v rc=$?; tail -1 $O/tests_$v.log
 done
