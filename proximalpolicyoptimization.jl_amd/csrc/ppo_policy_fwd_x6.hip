@@ -31,6 +31,13 @@
 #endif
 #define X6F_LANE() unsigned ln = (unsigned)lane; asm volatile("" : "+v"(ln)); const int j = (int)(ln & 31u), h = (int)(ln >> 5); (void)j; (void)h
 
+// A/B knob (make -C csrc fsidx): the one- and two-tile train forwards read their transition ids (the two-tile one also the active word of its tail) through the
+// scalar cache instead of vector loads + readfirstlane, each of which waits for vmcnt(0) -- every store and load in flight.
+// Not measured yet: off.
+#ifndef PPO_FX6_SIDX
+#define PPO_FX6_SIDX 0
+#endif
+
 template <int HID>
 struct FXCfg {
     static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;     // layer-1 k-steps: 72 inputs zero padded to 80
@@ -157,7 +164,14 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
         {
             unsigned ln2 = (unsigned)lane;
             asm volatile("" : "+v"(ln2));
+#if PPO_FX6_SIDX
+            {
+                const int32_t* const ip = a.idx + ntile;
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sid) : "s"(ip) : "memory");
+            }
+#else
             sid = __builtin_amdgcn_readfirstlane(a.idx[ntile]);
+#endif
             load_x(x_by_tile ? ntile : (int64_t)sid, ln2);
         }
         __syncthreads();                                                // (1) every layer-1 tile is in LDS
@@ -251,13 +265,6 @@ __global__ __launch_bounds__(HID * 2, 4) void k_policy_fwd_train_x6(FwdArgs a, c
 // through both layers against ONE pass over its weight stream: every W1 / W2 piece fragment feeds T MFMAs.  T x 48 KB of H1
 // fragments: one workgroup per CU, two waves per SIMD; the T independent accumulator chains per wave stand in for the second
 // workgroup's latency hiding.
-// A/B knob (make -C csrc fsidx): the two-tile train forward reads its transition ids (and the active word of the tail) through the
-// scalar cache instead of vector loads + readfirstlane, each of which waits for vmcnt(0) -- every store and load in flight.
-// Not measured yet: off.
-#ifndef PPO_FX6_SIDX
-#define PPO_FX6_SIDX 0
-#endif
-
 template <int HID, int T>
 struct FXTCfg {
     static constexpr int F = 72, NT = HID / 32, KS = HID / 16, K1 = 5;

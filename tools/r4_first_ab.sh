@@ -12,6 +12,12 @@ for r in 1 2; do for v in default fsidx xprio1 xprio2 xprio3; do
   [ -z "$L" ] || [ -f "$L" ] || { echo "missing $L"; continue; }
   PPO_HIP_LIB=$L timeout -k 10 60 python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/b_${v}_$r.json 2> $O/b_${v}_$r.err && python3 tools/show_bench.py $O/b_${v}_$r.json $v | cut -c1-170
 done; done
+# the 512-env strong-scaling shard (one-tile split forward) with and without the scalar-cache ids
+for r in 1 2; do for v in default fsidx; do
+  L=""; [ $v != default ] && L=$P/libppo_hip_$v.so
+  [ -z "$L" ] || [ -f "$L" ] || continue
+  PPO_HIP_LIB=$L PPO_BENCH_FORCE_DIST=1 timeout -k 10 60 python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --envs 512 > $O/s512_${v}_$r.json 2> $O/s512_${v}_$r.err && python3 tools/show_bench.py $O/s512_${v}_$r.json envs=512 $v | cut -c1-170
+done; done
 for v in fsidx xprio1 xprio2 xprio3; do
   [ -f $P/libppo_hip_$v.so ] || continue
   PPO_HIP_LIB=$P/libppo_hip_$v.so timeout -k 10 90 python3 -m pytest tests/test_gpu_split_backward.py -x -q > $O/tests_$v.log 2>&1; echo tests_$v rc=$?; tail -1 $O/tests_$v.log
