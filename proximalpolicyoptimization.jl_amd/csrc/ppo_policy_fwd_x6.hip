@@ -37,6 +37,12 @@
 #ifndef PPO_FX6_SIDX
 #define PPO_FX6_SIDX 0
 #endif
+// A/B knob (make -C csrc fzpipe): layer 2 of the two-tile train forward reads the H1 pieces one (k-step, tile) ahead of their MFMAs
+// (today each set is read right in front of its six MFMAs: two LDS latencies per k-step that only the SIMD partner can hide).
+// Not measured yet: off.
+#ifndef PPO_FX6_ZPIPE
+#define PPO_FX6_ZPIPE 0
+#endif
 
 template <int HID>
 struct FXCfg {
@@ -454,6 +460,18 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             const unsigned lo16 = ln * 16u;
             const char* zp = frag + lo16;
             const char* wn = w2s + (size_t)RD * 1024;
+#if PPO_FX6_ZPIPE
+            // the H1 pieces of the NEXT (k-step, tile) are read from the LDS in front of the six MFMAs of the current one (one
+            // set of lookahead, pinned), instead of right in front of the MFMAs that use them; the last set reads one k-step
+            // past this tile's fragments (the next tile's, or the partial-dot buffer: inside the LDS block, never used)
+            uint4 zc[3], zn[3];
+            auto load_z = [&](const char* zb, uint4 (&z)[3]) {
+                z[0] = *reinterpret_cast<const uint4*>(zb);
+                z[1] = *reinterpret_cast<const uint4*>(zb + 1024);
+                z[2] = *reinterpret_cast<const uint4*>(zb + 2048);
+            };
+            load_z(zp, zc);
+#endif
 #pragma unroll 1
             for (int k0 = 0; k0 < KS; k0 += RD / 3) {
 #pragma unroll
@@ -461,16 +479,27 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                     const uint4 wl = ring[3 * u + 0], wm = ring[3 * u + 1], wh = ring[3 * u + 2];
 #pragma unroll
                     for (int i = 0; i < T; ++i) {
+#if PPO_FX6_ZPIPE
+                        load_z(i + 1 < T ? zp + (size_t)(i + 1) * NT * 6 * 1024 + u * 3 * 1024 : zp + (u + 1) * 3 * 1024, zn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const uint4 z_h = zc[0], z_m = zc[1], z_l = zc[2];
+#else
                         const char* zi = zp + (size_t)i * NT * 6 * 1024;
                         const uint4 z_h = *reinterpret_cast<const uint4*>(zi + (u * 3 + 0) * 1024);
                         const uint4 z_m = *reinterpret_cast<const uint4*>(zi + (u * 3 + 1) * 1024);
                         const uint4 z_l = *reinterpret_cast<const uint4*>(zi + (u * 3 + 2) * 1024);
+#endif
                         accs[i] = x_mfma(wl, z_h, accs[i]);
                         accs[i] = x_mfma(wm, z_m, accs[i]);
                         accs[i] = x_mfma(wm, z_h, accs[i]);
                         accs[i] = x_mfma(wh, z_l, accs[i]);
                         accs[i] = x_mfma(wh, z_m, accs[i]);
                         acc[i] = x_mfma(wh, z_h, acc[i]);
+#if PPO_FX6_ZPIPE
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) zc[q] = zn[q];
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
