@@ -82,6 +82,9 @@ struct XCfg {
 #ifndef PPO_X6_PRIO
 #define PPO_X6_PRIO 0
 #endif
+#ifndef PPO_X6_ZPIPE
+#define PPO_X6_ZPIPE 0
+#endif
 #ifndef PPO_X6_RING
 #define PPO_X6_RING 6
 #endif
@@ -360,14 +363,35 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
             asm volatile("" : "+v"(zo));
             const char* zp = fragZ2 + zo;
             const unsigned lo16 = zo;
+#if PPO_X6_ZPIPE
+            // A/B knob: the dZ2 pieces of the next k-step are read in front of the current one's six MFMAs (12 more registers: only
+            // where the budget allows, i.e. HID = 128); the last read runs one k-step past the fragments (inside the LDS block)
+            constexpr bool ZP = HID <= 128;
+#else
+            constexpr bool ZP = false;
+#endif
+            uint4 zc[3] = {}, zn[3] = {};
+            if (ZP) {
+                zc[0] = *reinterpret_cast<const uint4*>(zp); zc[1] = *reinterpret_cast<const uint4*>(zp + 1024);
+                zc[2] = *reinterpret_cast<const uint4*>(zp + 2048);
+            }
 #pragma unroll 1
             for (int k0 = 0; k0 < KS; k0 += RU) {
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int s0 = (3 * u + 0) % RD, s1 = (3 * u + 1) % RD, s2 = (3 * u + 2) % RD;
-                    const uint4 z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
-                    const uint4 z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
-                    const uint4 z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
+                    uint4 z_h, z_m, z_l;
+                    if (ZP) {
+                        zn[0] = *reinterpret_cast<const uint4*>(zp + ((u + 1) * 3 + 0) * 1024);
+                        zn[1] = *reinterpret_cast<const uint4*>(zp + ((u + 1) * 3 + 1) * 1024);
+                        zn[2] = *reinterpret_cast<const uint4*>(zp + ((u + 1) * 3 + 2) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+                        z_h = zc[0]; z_m = zc[1]; z_l = zc[2];
+                    } else {
+                        z_h = *reinterpret_cast<const uint4*>(zp + (u * 3 + 0) * 1024);
+                        z_m = *reinterpret_cast<const uint4*>(zp + (u * 3 + 1) * 1024);
+                        z_l = *reinterpret_cast<const uint4*>(zp + (u * 3 + 2) * 1024);
+                    }
                     accs = x_mfma(z_h, ring[s0], accs);
                     __builtin_amdgcn_sched_barrier(0);
                     ring[s0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
@@ -384,6 +408,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                     ring[s2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
                     wn += 3 * 1024;
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ZP) { zc[0] = zn[0]; zc[1] = zn[1]; zc[2] = zn[2]; }
                 }
                 zp += RU * 3 * 1024;
             }
