@@ -85,6 +85,11 @@ struct XCfg {
 #ifndef PPO_X6_ZPIPE
 #define PPO_X6_ZPIPE 0
 #endif
+// A/B knob (make -C csrc xnodangle): the last ring round of the dH1 chain does not issue the reloads that run past the stream.
+// Not measured yet: off.
+#ifndef PPO_X6_NODANGLE
+#define PPO_X6_NODANGLE 0
+#endif
 #ifndef PPO_X6_RING
 #define PPO_X6_RING 6
 #endif
@@ -375,11 +380,18 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                 zc[0] = *reinterpret_cast<const uint4*>(zp); zc[1] = *reinterpret_cast<const uint4*>(zp + 1024);
                 zc[2] = *reinterpret_cast<const uint4*>(zp + 2048);
             }
-#pragma unroll 1
-            for (int k0 = 0; k0 < KS; k0 += RU) {
+            // one ring round (RU k-steps).  LAST: the round whose reloads would run past the wave's stream -- with PPO_X6_NODANGLE those
+            // loads are not issued (their registers are reused right behind the loop, and overwriting a register with a load in
+            // flight costs a vmcnt wait: one exposed L2 latency per tile)
+            auto chain_round = [&](auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int s0 = (3 * u + 0) % RD, s1 = (3 * u + 1) % RD, s2 = (3 * u + 2) % RD;
+                    // stream entry reloaded into slot s<pc>: 3 (k0 + u) + pc + RD, k0 = KS - RU in the last round
+                    const bool ld0 = !LAST || 3 * (KS - RU + u) + 0 + RD < 3 * KS;
+                    const bool ld1 = !LAST || 3 * (KS - RU + u) + 1 + RD < 3 * KS;
+                    const bool ld2 = !LAST || 3 * (KS - RU + u) + 2 + RD < 3 * KS;
                     uint4 z_h, z_m, z_l;
                     if (ZP) {
                         zn[0] = *reinterpret_cast<const uint4*>(zp + ((u + 1) * 3 + 0) * 1024);
@@ -394,24 +406,32 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_bwd_x6(BwdXArgs a) {
                     }
                     accs = x_mfma(z_h, ring[s0], accs);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[s0] = *reinterpret_cast<const uint4*>(wn + lo16);          // the last round reads RD KiB ahead (padding / next wave's stream)
+                    if (ld0) ring[s0] = *reinterpret_cast<const uint4*>(wn + lo16);   // (without PPO_X6_NODANGLE the last round reads RD KiB ahead: padding / next wave's stream)
                     __builtin_amdgcn_sched_barrier(0);
                     accs = x_mfma(z_m, ring[s1], accs);
                     accs = x_mfma(z_h, ring[s1], accs);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[s1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                    if (ld1) ring[s1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
                     __builtin_amdgcn_sched_barrier(0);
                     accs = x_mfma(z_l, ring[s2], accs);
                     accs = x_mfma(z_m, ring[s2], accs);
                     acc = x_mfma(z_h, ring[s2], acc);
                     __builtin_amdgcn_sched_barrier(0);
-                    ring[s2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                    if (ld2) ring[s2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
                     wn += 3 * 1024;
                     __builtin_amdgcn_sched_barrier(0);
                     if (ZP) { zc[0] = zn[0]; zc[1] = zn[1]; zc[2] = zn[2]; }
                 }
                 zp += RU * 3 * 1024;
-            }
+            };
+#if PPO_X6_NODANGLE
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS - RU; k0 += RU) chain_round(std::false_type{});
+            chain_round(std::true_type{});
+#else
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS; k0 += RU) chain_round(std::false_type{});
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = acc[r] + accs[r];
 #if PPO_X6_PRIO & 1

@@ -20,6 +20,7 @@
 // 0.211 -> 0.142 ms, 2048 0.110 -> 0.075, 1024 0.059 -> 0.039, 512 0.031 -> 0.023.  ppo_set_bwd_split_bf16(0) or
 // PPO_FWD_SPLIT_MAX_TILES=0 select the fp32-MFMA forward.
 #include "ppo_policy_tail.h"
+#include <type_traits>
 #include "ppo_x6.h"
 #include <cstdlib>
 
@@ -42,6 +43,21 @@
 // Not measured yet: off.
 #ifndef PPO_FX6_ZPIPE
 #define PPO_FX6_ZPIPE 0
+#endif
+// A/B knob (make -C csrc fxearly; implies the scalar-cache ids): the next pass's state rows are requested right after this pass's are
+// converted, behind a W1 ring that holds all 15 pieces -- vmcnt counts in order, so where they are issued today (in front of barrier 1,
+// behind the W2 ring fill) the first MFMA of layer 2 waits for them: one HBM latency per pass on all eight waves.  Not measured yet: off.
+#ifndef PPO_FX6_XEARLY
+#define PPO_FX6_XEARLY 0
+#endif
+#if PPO_FX6_XEARLY
+#undef PPO_FX6_SIDX
+#define PPO_FX6_SIDX 1
+#endif
+// A/B knob (make -C csrc fnodangle): the last ring round of layer 2 of the two-tile train forward does not issue the reloads that run
+// past the stream.  Not measured yet: off.
+#ifndef PPO_FX6_NODANGLE
+#define PPO_FX6_NODANGLE 0
 #endif
 
 template <int HID>
@@ -308,12 +324,28 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
     uint2 xr[T][K1];
     auto load_x = [&](int i, int64_t rec, unsigned ln) {
         const char* row = reinterpret_cast<const char*>(a.states) + (size_t)rec * 32 * F + (ln & 31u) * (unsigned)F + (ln >> 5) * 8u;
+#if PPO_FX6_XEARLY
+        // every load unconditional (the padding lanes of the last k-step re-read the row's first bytes and mask them with a value
+        // the compiler cannot see through): a load under an exec mask counts as "maybe not issued" in the compiler's vmcnt
+        // arithmetic, and the waits of layer 1 would then include the first state-row loads
+        unsigned keep = (ln >> 5) ? 0u : 0xFFFFFFFFu;
+        asm volatile("" : "+v"(keep));
+#pragma unroll
+        for (int s = 0; s < K1; ++s) {
+            const bool last = (s == K1 - 1);
+            unsigned off = (last && (ln >> 5)) ? 0u : (unsigned)(16 * s);
+            if (last) asm volatile("" : "+v"(off));
+            const uint2 v = *reinterpret_cast<const uint2*>(row + off);
+            xr[i][s] = last ? make_uint2(v.x & keep, v.y & keep) : v;
+        }
+#else
 #pragma unroll
         for (int s = 0; s < K1; ++s) {
             const bool pad = (s == K1 - 1) && (ln >> 5);
             const uint2 v = *reinterpret_cast<const uint2*>(row + (pad ? 0 : 16 * s));
             xr[i][s] = pad ? make_uint2(0u, 0u) : v;
         }
+#endif
     };
     // tile i of group g is g*T + i; a group that runs past the minibatch re-does the last tile and discards it
     auto tile_of = [&](int64_t g, int i) { const int64_t t = g * T + i; return t < a.B ? t : a.B - 1; };
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
         {
             X6F_LANE();
             unsigned lo16 = ln * 16u;
-            constexpr int R1 = 8;
+            constexpr int R1 = PPO_FX6_XEARLY ? 3 * K1 : 8;          // XEARLY: every W1 piece up front, no reload younger than the X loads below
             uint4 ring[R1];
 #pragma unroll
             for (int q = 0; q < R1; ++q) ring[q] = *reinterpret_cast<const uint4*>(w1s + (lo16 + (unsigned)q * 1024u));
@@ -370,6 +402,20 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                     xb[i][s] = make_uint4(x_perm(v[0], v[1]), x_perm(v[2], v[3]), x_perm(v[4], v[5]), x_perm(v[6], v[7]));
                 }
             }
+#if PPO_FX6_XEARLY
+            // the next pass's state rows leave for HBM here, as soon as this pass's are converted: they are younger than every W1
+            // piece (all loaded above), so no wait in layer 1 includes them, and layer 1 + the H1 epilogue (3-4 k clocks) pass before
+            // the first wait that does (the W2 ring in layer 2).  Issued in front of barrier 1, as before, that wait came
+            // a few hundred clocks after them.
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                const int64_t gn = ((g + gridDim.x) * T < a.B) ? g + gridDim.x : g;
+                sload_ids(gn, nid);
+#pragma unroll
+                for (int i = 0; i < T; ++i) load_x(i, x_by_tile ? tile_of(gn, i) : (int64_t)nid[i], ln);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
 #pragma unroll
             for (int st = 0; st < 3 * K1; ++st) {
 #pragma unroll
@@ -424,6 +470,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
 #pragma unroll
             for (int q = 0; q < RD; ++q) ring[q] = *reinterpret_cast<const uint4*>(w2s + (lo + (unsigned)q * 1024u));
         }
+#if !PPO_FX6_XEARLY
         {
             const int64_t gn = ((g + gridDim.x) * T < a.B) ? g + gridDim.x : g;
             unsigned ln2 = (unsigned)lane;
@@ -440,6 +487,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             }
 #endif
         }
+#endif
         FXSTAMP(2);
         __syncthreads();                                                // (1) every layer-1 tile of the T states is in LDS
         FXSTAMP(3);
@@ -472,6 +520,54 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
             };
             load_z(zp, zc);
 #endif
+#if PPO_FX6_NODANGLE
+            // one ring round (RD / 3 k-steps).  LAST (PPO_FX6_NODANGLE): the round whose reloads would run past the wave's stream does
+            // not issue them -- the ring registers are reused right behind the loop, and overwriting a register with a load in flight
+            // costs a vmcnt(0) wait there, which then also waits for the H2 stores of the first tile
+            auto l2_round = [&](auto last_c) {
+                constexpr bool LAST = decltype(last_c)::value;
+#pragma unroll
+                for (int u = 0; u < RD / 3; ++u) {
+                    const uint4 wl = ring[3 * u + 0], wm = ring[3 * u + 1], wh = ring[3 * u + 2];
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+#if PPO_FX6_ZPIPE
+                        load_z(i + 1 < T ? zp + (size_t)(i + 1) * NT * 6 * 1024 + u * 3 * 1024 : zp + (u + 1) * 3 * 1024, zn);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const uint4 z_h = zc[0], z_m = zc[1], z_l = zc[2];
+#else
+                        const char* zi = zp + (size_t)i * NT * 6 * 1024;
+                        const uint4 z_h = *reinterpret_cast<const uint4*>(zi + (u * 3 + 0) * 1024);
+                        const uint4 z_m = *reinterpret_cast<const uint4*>(zi + (u * 3 + 1) * 1024);
+                        const uint4 z_l = *reinterpret_cast<const uint4*>(zi + (u * 3 + 2) * 1024);
+#endif
+                        accs[i] = x_mfma(wl, z_h, accs[i]);
+                        accs[i] = x_mfma(wm, z_m, accs[i]);
+                        accs[i] = x_mfma(wm, z_h, accs[i]);
+                        accs[i] = x_mfma(wh, z_l, accs[i]);
+                        accs[i] = x_mfma(wh, z_m, accs[i]);
+                        acc[i] = x_mfma(wh, z_h, acc[i]);
+#if PPO_FX6_ZPIPE
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) zc[q] = zn[q];
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!LAST) {
+                        ring[3 * u + 0] = *reinterpret_cast<const uint4*>(wn + lo16);          // (without PPO_FX6_NODANGLE the last round reads RD KiB ahead: padding / next wave's stream)
+                        ring[3 * u + 1] = *reinterpret_cast<const uint4*>(wn + 1024 + lo16);
+                        ring[3 * u + 2] = *reinterpret_cast<const uint4*>(wn + 2048 + lo16);
+                        wn += 3 * 1024;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                zp += (RD / 3) * 3 * 1024;
+            };
+#pragma unroll 1
+            for (int k0 = 0; k0 < KS - RD / 3; k0 += RD / 3) l2_round(std::false_type{});
+            l2_round(std::true_type{});
+#else
 #pragma unroll 1
             for (int k0 = 0; k0 < KS; k0 += RD / 3) {
 #pragma unroll
@@ -510,6 +606,7 @@ __global__ __launch_bounds__(HID * 2, 2) void k_policy_fwd_train_x6t(FwdArgs a, 
                 }
                 zp += (RD / 3) * 3 * 1024;
             }
+#endif
             FXSTAMP(4);
 #pragma unroll
             for (int i = 0; i < T; ++i) {
