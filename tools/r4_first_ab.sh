@@ -5,11 +5,13 @@
 # in the last ring round (fnodangle, xnodangle; fall = every forward knob so far), (5) the next pass's state rows requested early in layer 1
 # (fxearly; fbest = fxearly + fnodangle + fzpipe).  DESIGN.md section 9 item 0 has the reasoning.
 # Build first: make -C proximalpolicyoptimization.jl_amd/csrc xprio fsidx fzpipe xzpipe xnodangle fnodangle fxearly   (the .so files travel with the snapshot)
-# usage (on the box): bash tools/r4_first_ab.sh [outdir]
+# usage (on the box): bash tools/r4_first_ab.sh [outdir] [bench|tests]   (both by default: ~10 minutes, give gpurun --timeout 1000)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/${1:-xprio}; mkdir -p $O
 P=$GRAFT_REPO_ROOT/proximalpolicyoptimization.jl_amd
+MODE=${2:-both}
+if [ $MODE != tests ]; then
 for r in 1 2; do for v in default fsidx fzpipe fzs fnodangle fall fxearly fbest xnodangle xprio1 xprio2 xprio3; do
   L=""; [ $v != default ] && L=$P/libppo_hip_$v.so
   [ -z "$L" ] || [ -f "$L" ] || { echo "missing $L"; continue; }
@@ -27,6 +29,8 @@ for r in 1 2; do for v in default fsidx; do
   [ -z "$L" ] || [ -f "$L" ] || continue
   PPO_HIP_LIB=$L PPO_BENCH_FORCE_DIST=1 timeout -k 10 60 python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --envs 512 > $O/s512_${v}_$r.json 2> $O/s512_${v}_$r.err && python3 tools/show_bench.py $O/s512_${v}_$r.json envs=512 $v | cut -c1-170
 done; done
+fi
+[ $MODE = bench ] && exit 0
 for v in fsidx fzpipe fzs fnodangle fall fxearly fbest xnodangle xzpipe xprio1 xprio2 xprio3; do
   [ -f $P/libppo_hip_$v.so ] || continue
   PPO_HIP_LIB=$P/libppo_hip_$v.so timeout -k 10 90 python3 -m pytest tests/test_gpu_split_backward.py -x -q > $O/tests_$v.log 2>&1; echo tests_$v rc=$?; tail -1 $O/tests_$v.log
